@@ -1,0 +1,292 @@
+"""ctypes mirror of include/ubdpt.h and loader of the HIP backend (libubdpt.so).
+
+Harness-side plumbing only: bench.py, __graft_entry__.py and tests/ drive the C ABI through this
+module. There is no CPU fallback: if the shared library is missing or no GPU is present the calls
+raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libubdpt.so")
+
+# status codes (include/ubdpt.h)
+SUCCESS, UNINITIALIZED, INVALID_SCENE, INVALID_FORMAT, STOPPED, NO_DATA, ERROR, INVALID_ARG, NO_DEVICE, HIP_ERROR = range(10)
+MODEL_SPHERE, MODEL_MESH = 0, 1
+MAT_LATEX_PAINT, MAT_GLOSSY, MAT_PERFECT_MIRROR, MAT_DIELECTRIC = 0, 1, 2, 3
+TEX_COLOR, TEX_IMAGE = 0, 1
+LOBE_NONE, LOBE_LAMBERTIAN, LOBE_MIRROR, LOBE_DIELECTRIC = -1, 0, 1, 2
+MAX_KERNEL_STATS = 24
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("look_at", C.c_double * 3), ("vfov", C.c_double), ("ratio", C.c_double)]
+
+
+class RenderParams(C.Structure):
+    _fields_ = [("img_res_x", C.c_uint64), ("img_res_y", C.c_uint64), ("pixel_subdiv", C.c_uint64),
+                ("lens_subdiv", C.c_uint64), ("min_depth", C.c_uint64), ("focus_plane_distance", C.c_double),
+                ("lens_size", C.c_double)]
+
+
+class MeshVertex(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("normal", C.c_float * 3), ("tangent", C.c_float * 3), ("uv", C.c_float * 2)]
+
+
+MESH_VERTEX_DTYPE = np.dtype([("pos", "<f4", 3), ("normal", "<f4", 3), ("tangent", "<f4", 3), ("uv", "<f4", 2)])
+
+
+class Texture(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32), ("reserved", C.c_uint32),
+                ("color", C.c_double * 3), ("texel_offset", C.c_uint64)]
+
+
+class Object(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("material", C.c_uint32), ("W", C.c_double * 16), ("mat_a", C.c_double),
+                ("mat_b", C.c_double), ("texture", C.c_uint32), ("is_emitter", C.c_uint32), ("power", C.c_double * 3),
+                ("first_face", C.c_uint64), ("num_faces", C.c_uint64)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("camera", Camera), ("num_objects", C.c_uint32), ("num_textures", C.c_uint32),
+                ("objects", C.POINTER(Object)), ("textures", C.POINTER(Texture)), ("num_faces", C.c_uint64),
+                ("vertices", C.POINTER(MeshVertex)), ("num_texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8))]
+
+
+class Options(C.Structure):
+    _fields_ = [("max_path_vertices", C.c_uint32), ("passes_in_flight", C.c_uint32), ("accel", C.c_uint32),
+                ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3)])
+HIT_DTYPE = np.dtype([("hit", "<i4"), ("object", "<i4"), ("face", "<i8"), ("d", "<f8"), ("pos", "<f8", 3),
+                      ("Ng", "<f8", 3), ("Ns", "<f8", 3), ("Ts", "<f8", 3), ("Bs", "<f8", 3), ("tex_u", "<f8"),
+                      ("tex_v", "<f8")])
+SEGMENT_DTYPE = np.dtype([("p0", "<f8", 3), ("p1", "<f8", 3)])
+BSDF_QUERY_DTYPE = np.dtype([("lobe", "<i4"), ("reserved", "<i4"), ("eta", "<f8"), ("tex", "<f8", 3),
+                             ("frame", "<f8", 12), ("wi", "<f8", 3), ("wo", "<f8", 3), ("u1", "<f8"), ("u2", "<f8")])
+BSDF_RESULT_DTYPE = np.dtype([("f", "<f8", 3), ("pdf", "<f8"), ("dir", "<f8", 3), ("ok", "<i4"), ("specular", "<i4")])
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 40), ("launches", C.c_uint64), ("ms", C.c_double), ("units", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("passes", C.c_uint64), ("pixel_samples", C.c_uint64), ("closest_hit_rays", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("eye_vertices", C.c_uint64), ("light_vertices", C.c_uint64),
+                ("connections", C.c_uint64), ("splats", C.c_uint64), ("bvh_nodes_visited", C.c_uint64),
+                ("prims_tested", C.c_uint64), ("capped_subpaths", C.c_uint64), ("render_seconds", C.c_double),
+                ("build_seconds", C.c_double), ("num_kernel_stats", C.c_uint32), ("reserved", C.c_uint32),
+                ("kernels", KernelStat * MAX_KERNEL_STATS)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("kernels", "reserved", "num_kernel_stats")}
+        d["kernels"] = [
+            {"name": self.kernels[i].name.decode(), "launches": self.kernels[i].launches, "ms": self.kernels[i].ms,
+             "units": self.kernels[i].units} for i in range(self.num_kernel_stats)]
+        return d
+
+
+# Every entry point include/ubdpt.h declares; tests check that the library exports all of them.
+EXPORTS = [
+    "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
+    "ubdpt_render_passes", "ubdpt_request_stop", "ubdpt_read_sum", "ubdpt_read_sum_device", "ubdpt_upload_sum",
+    "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
+    "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
+    "ubdpt_bsdf_scatter_batch",
+]
+
+
+class FlatScene:
+    """Owns the numpy/ctypes storage behind a SceneDesc (keeps the buffers alive)."""
+
+    def __init__(self, camera, objects, vertices, textures, texels=None):
+        self.camera = camera
+        self.objects = (Object * max(1, len(objects)))(*objects)
+        self.n_objects = len(objects)
+        self.textures = (Texture * max(1, len(textures)))(*textures)
+        self.n_textures = len(textures)
+        self.vertices = np.ascontiguousarray(vertices, dtype=MESH_VERTEX_DTYPE)
+        assert self.vertices.size % 3 == 0
+        self.texels = np.ascontiguousarray(texels if texels is not None else np.zeros(0, np.uint8), dtype=np.uint8)
+        self.desc = SceneDesc()
+        self.desc.camera = camera
+        self.desc.num_objects = self.n_objects
+        self.desc.num_textures = self.n_textures
+        self.desc.objects = C.cast(self.objects, C.POINTER(Object))
+        self.desc.textures = C.cast(self.textures, C.POINTER(Texture))
+        self.desc.num_faces = self.vertices.size // 3
+        self.desc.vertices = self.vertices.ctypes.data_as(C.POINTER(MeshVertex))
+        self.desc.num_texel_bytes = self.texels.size
+        self.desc.texels = self.texels.ctypes.data_as(C.POINTER(C.c_uint8))
+
+    @property
+    def num_faces(self):
+        return self.vertices.size // 3
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads libubdpt.so (no fallback)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"HIP backend library not built: {p} (run `make -C bidirectional-pathtracing_amd/csrc`)")
+    lib = C.CDLL(p)
+    vp = C.c_void_p
+    lib.ubdpt_version.restype = C.c_int
+    lib.ubdpt_status_string.restype = C.c_char_p
+    lib.ubdpt_status_string.argtypes = [C.c_int]
+    lib.ubdpt_device_count.argtypes = [C.POINTER(C.c_int)]
+    lib.ubdpt_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderParams), C.POINTER(Options), C.c_int, C.POINTER(vp)]
+    lib.ubdpt_destroy.argtypes = [vp]
+    lib.ubdpt_render_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.ubdpt_request_stop.argtypes = [vp]
+    lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
+    lib.ubdpt_read_sum_device.argtypes = [vp, vp]
+    lib.ubdpt_upload_sum.argtypes = [vp, vp]
+    lib.ubdpt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.ubdpt_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.ubdpt_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
+    lib.ubdpt_get_camera_info.argtypes = [vp, vp, vp, vp]
+    lib.ubdpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    lib.ubdpt_reset_stats.argtypes = [vp]
+    for n in ("ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch", "ubdpt_bsdf_scatter_batch"):
+        getattr(lib, n).argtypes = [vp, vp, C.c_size_t, vp]
+    for n in EXPORTS:
+        if n not in ("ubdpt_status_string",):
+            getattr(lib, n).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class UbdptError(RuntimeError):
+    def __init__(self, status, what):
+        self.status = status
+        try:
+            msg = load_library().ubdpt_status_string(status).decode()
+        except Exception:  # pragma: no cover
+            msg = "?"
+        super().__init__(f"{what}: status {status} ({msg})")
+
+
+def _check(status, what, allow=()):
+    if status != SUCCESS and status not in allow:
+        raise UbdptError(status, what)
+    return status
+
+
+class Context:
+    """Thin object wrapper over ubdpt_context*."""
+
+    def __init__(self, scene: FlatScene, params: RenderParams, options: Options = None, device: int = 0):
+        self.lib = load_library()
+        self.scene = scene
+        self.params = params
+        self.width, self.height = int(params.img_res_x), int(params.img_res_y)
+        self.handle = C.c_void_p()
+        opt = C.byref(options) if options is not None else None
+        _check(self.lib.ubdpt_create(C.byref(scene.desc), C.byref(params), opt, device, C.byref(self.handle)),
+               "ubdpt_create")
+
+    def close(self):
+        if self.handle:
+            self.lib.ubdpt_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_passes(self, first_pass, n_passes, seed, pass_stride=1):
+        done = C.c_uint32(0)
+        st = self.lib.ubdpt_render_passes(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
+        _check(st, "ubdpt_render_passes", allow=(STOPPED,))
+        return st, done.value
+
+    def request_stop(self):
+        _check(self.lib.ubdpt_request_stop(self.handle), "ubdpt_request_stop")
+
+    def read_sum(self, out=None, add_into=False):
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (self.height, self.width, 3)
+        _check(self.lib.ubdpt_read_sum(self.handle, out.ctypes.data, 1 if add_into else 0), "ubdpt_read_sum")
+        return out
+
+    def read_sum_device(self, device_ptr):
+        _check(self.lib.ubdpt_read_sum_device(self.handle, device_ptr), "ubdpt_read_sum_device")
+
+    def upload_sum(self, rgb):
+        if rgb is None:
+            _check(self.lib.ubdpt_upload_sum(self.handle, None), "ubdpt_upload_sum")
+            return
+        rgb = np.ascontiguousarray(rgb, np.float64)
+        assert rgb.shape == (self.height, self.width, 3)
+        _check(self.lib.ubdpt_upload_sum(self.handle, rgb.ctypes.data), "ubdpt_upload_sum")
+
+    def intersect_batch(self, rays):
+        rays = np.ascontiguousarray(rays, RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], HIT_DTYPE)
+        _check(self.lib.ubdpt_intersect_batch(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data),
+               "ubdpt_intersect_batch")
+        return hits
+
+    def visibility_batch(self, segs):
+        segs = np.ascontiguousarray(segs, SEGMENT_DTYPE)
+        vis = np.zeros(segs.shape[0], np.uint8)
+        _check(self.lib.ubdpt_visibility_batch(self.handle, segs.ctypes.data, segs.shape[0], vis.ctypes.data),
+               "ubdpt_visibility_batch")
+        return vis
+
+    def object_info(self, i):
+        invW = np.zeros(16); bs = np.zeros(16)
+        area = C.c_double(); prob = C.c_double()
+        _check(self.lib.ubdpt_get_object_info(self.handle, i, invW.ctypes.data, C.addressof(area), C.addressof(prob),
+                                              bs.ctypes.data), "ubdpt_get_object_info")
+        return invW, area.value, prob.value, bs
+
+    def camera_info(self):
+        v = np.zeros(16); iv = np.zeros(16); d = C.c_double()
+        _check(self.lib.ubdpt_get_camera_info(self.handle, v.ctypes.data, iv.ctypes.data, C.addressof(d)),
+               "ubdpt_get_camera_info")
+        return v, iv, d.value
+
+    def stats(self):
+        s = Stats()
+        _check(self.lib.ubdpt_get_stats(self.handle, C.byref(s)), "ubdpt_get_stats")
+        return s.as_dict()
+
+    def reset_stats(self):
+        _check(self.lib.ubdpt_reset_stats(self.handle), "ubdpt_reset_stats")
+
+    def _bsdf(self, fn, q):
+        q = np.ascontiguousarray(q, BSDF_QUERY_DTYPE)
+        r = np.zeros(q.shape[0], BSDF_RESULT_DTYPE)
+        _check(fn(self.handle, q.ctypes.data, q.shape[0], r.ctypes.data), "ubdpt_bsdf_*")
+        return r
+
+    def bsdf_eval(self, q):
+        return self._bsdf(self.lib.ubdpt_bsdf_eval_batch, q)
+
+    def bsdf_pdf(self, q):
+        return self._bsdf(self.lib.ubdpt_bsdf_pdf_batch, q)
+
+    def bsdf_scatter(self, q):
+        return self._bsdf(self.lib.ubdpt_bsdf_scatter_batch, q)

@@ -1,0 +1,273 @@
+/*
+ * ubdpt.h — C ABI of the MI355X bidirectional-path-tracing backend.
+ *
+ * This is the drop-in boundary for the reference's renderer plug-in point
+ *   class URenderer { initialize / renderPass / stop }   (uengine/urenderer.h:10-16)
+ * as it is driven by UEngine                              (uengine/uengine.cpp:33-63,144-180,204-208).
+ * A URenderer subclass living in the reference tree forwards to these entry points
+ * (binding shown in INTEGRATION.md). Only plain pointers, sizes and POD structs cross
+ * the boundary; every function returns an int status and never throws.
+ *
+ * Because UScene exposes geometry only through opaque virtuals
+ * (uengine/uscene.h:16-18, uengine/uobject.h:14-18) the scene crosses the boundary as a
+ * flat description that carries exactly the data the reference's uapp classes hold:
+ *   Object   {W, material, model}            uapp/object.h:10-24
+ *   Emitter  {power}                         uapp/emitter.cpp:3-7
+ *   Mesh     {faces of 3 x MeshVertex}       uapp/mesh.h:13-22  (floats, as assimp delivers them, uapp/mesh.cpp:20-30)
+ *   Material {LatexPaint, Glossy(d,s), PerfectMirror, Dielectric(eta)}   uapp/material.h:17-104
+ *   Texture  {TextureColor, TextureImg}      uapp/texturecolor.cpp:3-11, uapp/textureimg.cpp:19-33
+ *   UCamera  {ratio, vfov, pos, lookAt}      uengine/ucamera.cpp:3-14
+ * Everything derived (inverse matrices, areas, emitter pick probabilities, mesh bounding
+ * spheres, face pick probabilities, view matrix, acceleration structure) is computed by
+ * the library, following the reference.
+ */
+#ifndef UBDPT_H
+#define UBDPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: superset of UResult (uengine/uengine.h:18), same order for the shared part ---- */
+enum {
+    UBDPT_SUCCESS        = 0, /* UResult::USuccess       */
+    UBDPT_UNINITIALIZED  = 1, /* UResult::UUninitialized */
+    UBDPT_INVALID_SCENE  = 2, /* UResult::UInvalidScene  */
+    UBDPT_INVALID_FORMAT = 3, /* UResult::UInvalidFormat */
+    UBDPT_STOPPED        = 4, /* UResult::UStopped       */
+    UBDPT_NO_DATA        = 5, /* UResult::UNoData        */
+    UBDPT_ERROR          = 6, /* UResult::UError         */
+    UBDPT_INVALID_ARG    = 7,
+    UBDPT_NO_DEVICE      = 8,
+    UBDPT_HIP_ERROR      = 9
+};
+
+/* ---- scene description ---- */
+enum { UBDPT_MODEL_SPHERE = 0, UBDPT_MODEL_MESH = 1 };
+/* material kinds, uapp/material.h */
+enum { UBDPT_MAT_LATEX_PAINT = 0, UBDPT_MAT_GLOSSY = 1, UBDPT_MAT_PERFECT_MIRROR = 2, UBDPT_MAT_DIELECTRIC = 3 };
+enum { UBDPT_TEX_COLOR = 0, UBDPT_TEX_IMAGE = 1 };
+/* BSDF lobe ids as stored in hit records and path vertices (uengine/ubsdf*.h); -1 = no lobe (absorbed) */
+enum { UBDPT_LOBE_NONE = -1, UBDPT_LOBE_LAMBERTIAN = 0, UBDPT_LOBE_MIRROR = 1, UBDPT_LOBE_DIELECTRIC = 2 };
+
+/* UCamera constructor arguments (uengine/ucamera.cpp:3-14); up vector is always (0,1,0). */
+typedef struct ubdpt_camera {
+    double pos[3];
+    double look_at[3];
+    double vfov;   /* vertical field of view, radians */
+    double ratio;  /* width / height */
+} ubdpt_camera;
+
+/* Same members, order and size (56 bytes on LP64) as URenderParameters (uengine/uutils.h:11-20). */
+typedef struct ubdpt_render_params {
+    uint64_t img_res_x;
+    uint64_t img_res_y;
+    uint64_t pixel_subdiv;
+    uint64_t lens_subdiv;
+    uint64_t min_depth;
+    double   focus_plane_distance;
+    double   lens_size;
+} ubdpt_render_params;
+
+/* One corner of a mesh face: the float data aiMesh holds (uapp/mesh.cpp:14-32). 44 bytes. */
+typedef struct ubdpt_mesh_vertex {
+    float pos[3];
+    float normal[3];
+    float tangent[3];
+    float uv[2];
+} ubdpt_mesh_vertex;
+
+typedef struct ubdpt_texture {
+    uint32_t kind;          /* UBDPT_TEX_* */
+    uint32_t width, height; /* image only */
+    uint32_t reserved;
+    double   color[3];      /* TextureColor value */
+    uint64_t texel_offset;  /* byte offset of this image's RGBA8888 rows inside scene.texels */
+} ubdpt_texture;
+
+typedef struct ubdpt_object {
+    uint32_t kind;        /* UBDPT_MODEL_* */
+    uint32_t material;    /* UBDPT_MAT_* */
+    double   W[16];       /* object-to-world, column-major like glm::dmat4x4 */
+    double   mat_a;       /* Glossy: d;  Dielectric: eta */
+    double   mat_b;       /* Glossy: s */
+    uint32_t texture;     /* index into scene.textures */
+    uint32_t is_emitter;  /* non-zero: uapp Emitter (object AND emitter, uapp/scene.cpp:232-237) */
+    double   power[3];    /* emitter power */
+    uint64_t first_face;  /* mesh: first face in scene.vertices (3 vertices per face) */
+    uint64_t num_faces;   /* mesh: number of faces */
+} ubdpt_object;
+
+/* Object order is the order of UScene::objects(); emitters keep their relative order
+ * (UScene::emitters()), both matter for tie-breaks and emitter selection. */
+typedef struct ubdpt_scene_desc {
+    ubdpt_camera             camera;
+    uint32_t                 num_objects;
+    uint32_t                 num_textures;
+    const ubdpt_object*      objects;
+    const ubdpt_texture*     textures;
+    uint64_t                 num_faces;     /* total faces of all meshes */
+    const ubdpt_mesh_vertex* vertices;      /* 3 * num_faces */
+    uint64_t                 num_texel_bytes;
+    const uint8_t*           texels;        /* RGBA8888 */
+} ubdpt_scene_desc;
+
+/* Backend knobs that have no counterpart in the reference. Zero-initialise for defaults. */
+typedef struct ubdpt_options {
+    uint32_t max_path_vertices; /* cap on vertices per subpath (reference: unbounded); 0 -> 32 */
+    uint32_t passes_in_flight;  /* passes rendered concurrently by one wavefront batch; 0 -> auto */
+    uint32_t accel;             /* 0 = LBVH, 1 = linear scan over all primitives (reference order) */
+    uint32_t collect_stats;     /* non-zero: count rays / vertices / traversal steps (slower) */
+    uint32_t pipeline;          /* 0 = default pipeline; others select experimental variants */
+    uint32_t reserved[3];
+} ubdpt_options;
+
+/* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */
+typedef struct ubdpt_ray {      /* URay: origin (w=1) and direction (w=0), uengine/ugeometry.h:35-37 */
+    double origin[3];
+    double dir[3];
+} ubdpt_ray;
+
+typedef struct ubdpt_hit {      /* the fields UScene::intersectionPoint fills in USurfacePoint (uengine/uutils.h:22-35) */
+    int32_t  hit;               /* 0 / 1 */
+    int32_t  object;            /* index in scene.objects, -1 if none */
+    int64_t  face;              /* face index inside the object's mesh, -1 for spheres / miss */
+    double   d;                 /* ray parameter of the hit (object-local == world, uengine/ugeometry.cpp:55-58) */
+    double   pos[3];            /* object-local, like USurfacePoint before renderer transforms it */
+    double   Ng[3], Ns[3], Ts[3], Bs[3];
+    double   tex_u, tex_v;
+} ubdpt_hit;
+
+typedef struct ubdpt_segment {  /* UScene::visibility(p0, p1) arguments */
+    double p0[3];
+    double p1[3];
+} ubdpt_segment;
+
+/* ---- statistics ---- */
+#define UBDPT_MAX_KERNEL_STATS 24
+typedef struct ubdpt_kernel_stat {
+    char     name[40];
+    uint64_t launches;
+    double   ms;        /* HIP-event time on the backend's own stream, summed over launches */
+    double   units;     /* work items summed over launches (rays, vertices, pixel-samples ...) */
+} ubdpt_kernel_stat;
+
+typedef struct ubdpt_stats {
+    uint64_t passes;            /* passes rendered since create / reset */
+    uint64_t pixel_samples;     /* renderPixel invocations = paths */
+    uint64_t closest_hit_rays;  /* UScene::intersectionPoint calls (only with collect_stats) */
+    uint64_t shadow_rays;       /* UScene::visibility calls actually traced (only with collect_stats) */
+    uint64_t eye_vertices;      /* stored eye-subpath vertices incl. lens vertex (collect_stats) */
+    uint64_t light_vertices;    /* stored light-subpath vertices incl. emitter vertex (collect_stats) */
+    uint64_t connections;       /* (s,t) pairs that contributed (collect_stats) */
+    uint64_t splats;            /* t==1 atomic splats (collect_stats) */
+    uint64_t bvh_nodes_visited; /* traversal steps (collect_stats) */
+    uint64_t prims_tested;      /* primitive tests (collect_stats) */
+    uint64_t capped_subpaths;   /* subpaths that hit max_path_vertices (collect_stats) */
+    double   render_seconds;    /* host wall time inside ubdpt_render_passes, incl. final sync */
+    double   build_seconds;     /* scene upload + acceleration structure build */
+    uint32_t num_kernel_stats;
+    uint32_t reserved;
+    ubdpt_kernel_stat kernels[UBDPT_MAX_KERNEL_STATS];
+} ubdpt_stats;
+
+typedef struct ubdpt_context ubdpt_context;
+
+/* Library / device probes. */
+int         ubdpt_version(void);
+const char* ubdpt_status_string(int status);
+int         ubdpt_device_count(int* count);
+
+/*
+ * URenderer::initialize (uengine/ubdptrenderer.cpp:7-33) + UEngine::setScene's
+ * computeEmitterProbabilities (uengine/uengine.cpp:15-20, uengine/uscene.cpp:4-19) +
+ * UEngine::initPixelBuffers (uengine/uengine.cpp:22-31): flattens the scene onto the device,
+ * builds the acceleration structure and allocates the zeroed W x H sum buffer.
+ * `options` may be NULL.
+ */
+int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* params,
+                 const ubdpt_options* options, int device, ubdpt_context** out);
+
+/* Releases everything ubdpt_create allocated (UEngine drops its unique_ptr<URenderer>, uengine/uengine.h:62). */
+int ubdpt_destroy(ubdpt_context* ctx);
+
+/*
+ * URenderer::renderPass (uengine/ubdptrenderer.cpp:35-81) for passes
+ * first_pass, first_pass + pass_stride, ... (n_passes of them): every pass adds one
+ * renderPixel sample (uengine/ubdptrenderer.cpp:88-154) per pixel into the device sum buffer,
+ * strata chosen by the pass index (:95-96). pass_stride > 1 is the multi-GPU partition.
+ * Returns UBDPT_STOPPED if ubdpt_request_stop arrived; passes already finished stay accumulated
+ * and *passes_done (may be NULL) tells how many.
+ */
+int ubdpt_render_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
+                        uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
+
+/* URenderer::stop (uengine/ubdptrenderer.cpp:83-86): callable from any thread. */
+int ubdpt_request_stop(ubdpt_context* ctx);
+
+/*
+ * The sum buffer UEngine hands to renderPass (uengine/uengine.cpp:153-164): H x W x 3 doubles,
+ * row-major [y][x][rgb] exactly like UBuffer2D<glm::dvec3> (uengine/uutils.h:37-98).
+ * add_into != 0: rgb[i] += device sum (the adapter's "add this pass to the engine's buffer");
+ * add_into == 0: rgb[i]  = device sum.
+ */
+int ubdpt_read_sum(ubdpt_context* ctx, double* rgb, int add_into);
+/* Same data, but written to DEVICE memory owned by the caller (e.g. a buffer handed to an RCCL reduce). */
+int ubdpt_read_sum_device(ubdpt_context* ctx, double* device_rgb);
+/* Replaces the device sum (resume from a .ur file, uengine/uengine.cpp:107-116). NULL clears it. */
+int ubdpt_upload_sum(ubdpt_context* ctx, const double* rgb);
+
+/* UScene::intersectionPoint (uengine/uscene.cpp:41-66) for n rays, through the backend's accelerator. */
+int ubdpt_intersect_batch(ubdpt_context* ctx, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);
+/* UScene::visibility (uengine/uscene.cpp:21-39) for n point pairs: visible[i] = 1 / 0. */
+int ubdpt_visibility_batch(ubdpt_context* ctx, const ubdpt_segment* segs, size_t n, uint8_t* visible);
+
+/*
+ * Derived per-object data, for checking the flattening against the reference's constructors:
+ * invW (uapp/object.cpp:8), area (uapp/emitter.cpp:6), pick probability (uengine/uscene.cpp:4-19),
+ * bounding-sphere matrix (uapp/mesh.cpp:38-86; identity for spheres). Any out pointer may be NULL.
+ */
+int ubdpt_get_object_info(ubdpt_context* ctx, uint32_t object, double invW[16], double* area,
+                          double* probability, double bounding_sphere[16]);
+/* View matrix and image-plane distance the renderer snapshots (uengine/ubdptrenderer.cpp:11-14). */
+int ubdpt_get_camera_info(ubdpt_context* ctx, double view[16], double inv_view[16], double* image_plane_distance);
+
+int ubdpt_get_stats(ubdpt_context* ctx, ubdpt_stats* out);
+int ubdpt_reset_stats(ubdpt_context* ctx);
+
+/*
+ * BSDF probes (UBsdf::samplePSA / pPSA / scatter, uengine/ubsdf.h:22-38), evaluated on the device
+ * for n independent queries. lobe = UBDPT_LOBE_*; eta is used by the dielectric; tex is the texture value.
+ * frame = Ng, Ns, Ts, Bs (4 x 3 doubles). For scatter, u1/u2 are the uniform numbers the reference
+ * would draw, in its draw order.
+ */
+typedef struct ubdpt_bsdf_query {
+    int32_t lobe;
+    int32_t reserved;
+    double  eta;
+    double  tex[3];
+    double  frame[12];
+    double  wi[3];     /* samplePSA: wiT; pPSA: wsT; scatter: w (same space as frame) */
+    double  wo[3];     /* samplePSA: woT; pPSA: wgT */
+    double  u1, u2;
+} ubdpt_bsdf_query;
+
+typedef struct ubdpt_bsdf_result {
+    double  f[3];      /* samplePSA value / scatter's bsdf_samplePSA */
+    double  pdf;       /* pPSA value / scatter's pPSA */
+    double  dir[3];    /* scatter's scat_dirT */
+    int32_t ok;        /* scatter's return value */
+    int32_t specular;
+} ubdpt_bsdf_result;
+
+int ubdpt_bsdf_eval_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);
+int ubdpt_bsdf_pdf_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);
+int ubdpt_bsdf_scatter_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UBDPT_H */

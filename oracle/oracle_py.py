@@ -1,0 +1,164 @@
+"""ctypes binding of the CPU oracle (oracle/libbdpt_oracle.so). TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the backend."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+capi = importlib.import_module("bidirectional-pathtracing_amd.capi")
+
+LIB_PATH = os.path.join(HERE, "libbdpt_oracle.so")
+
+VERTEX_DTYPE = np.dtype([("pos", "<f8", 3), ("Ng", "<f8", 3), ("Ns", "<f8", 3), ("Ts", "<f8", 3), ("Bs", "<f8", 3),
+                         ("tex_u", "<f8"), ("tex_v", "<f8"), ("a", "<f8", 3), ("p_light_A", "<f8"),
+                         ("p_eye_A", "<f8"), ("object", "<i4"), ("lobe", "<i4"), ("specular", "<i4"),
+                         ("reserved", "<i4")])
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("pixel_samples", "closest_hit_rays", "shadow_rays", "eye_vertices",
+                                          "light_vertices", "connections", "splats", "capped_subpaths",
+                                          "prims_tested")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"oracle not built: {LIB_PATH} (run `make -C oracle`)")
+        l = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        l.oracle_create.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.RenderParams), C.c_uint32, C.POINTER(vp)]
+        l.oracle_destroy.argtypes = [vp]
+        l.oracle_destroy.restype = None
+        l.oracle_render_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, vp,
+                                           C.POINTER(Counters)]
+        l.oracle_trace_pixel.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32),
+                                         vp, C.POINTER(C.c_uint32), vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
+        l.oracle_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
+        l.oracle_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
+        l.oracle_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
+        l.oracle_get_camera_info.argtypes = [vp, vp, vp, vp]
+        for n in ("oracle_bsdf_eval_batch", "oracle_bsdf_pdf_batch", "oracle_bsdf_scatter_batch"):
+            getattr(l, n).argtypes = [vp, C.c_size_t, vp]
+        l.oracle_texture_sample_batch.argtypes = [vp, C.c_uint32, vp, C.c_size_t, vp]
+        l.oracle_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+        l.oracle_uniform.restype = C.c_double
+        l.oracle_sample_map.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, vp]
+        _lib = l
+    return _lib
+
+
+class Oracle:
+    def __init__(self, scene, params, max_path_vertices=32):
+        self.lib = lib()
+        self.scene, self.params = scene, params
+        self.width, self.height = int(params.img_res_x), int(params.img_res_y)
+        self.max_path_vertices = max_path_vertices
+        self.handle = C.c_void_p()
+        st = self.lib.oracle_create(C.byref(scene.desc), C.byref(params), max_path_vertices, C.byref(self.handle))
+        if st != 0:
+            raise RuntimeError(f"oracle_create failed: {st}")
+
+    def close(self):
+        if self.handle:
+            self.lib.oracle_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render_passes(self, first_pass, n_passes, seed, pass_stride=1, num_threads=1, out=None, counters=False):
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), np.float64)
+        cn = Counters()
+        st = self.lib.oracle_render_passes(self.handle, first_pass, n_passes, pass_stride, seed, num_threads,
+                                           out.ctypes.data, C.byref(cn) if counters else None)
+        assert st == 0
+        return (out, cn.as_dict()) if counters else out
+
+    def trace_pixel(self, pass_idx, seed, px, py, max_splats=64):
+        eye = np.zeros(self.max_path_vertices + 1, VERTEX_DTYPE)
+        light = np.zeros(self.max_path_vertices + 1, VERTEX_DTYPE)
+        ne, nl, ns = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        I = np.zeros(3)
+        splats = np.zeros((max_splats, 5))
+        st = self.lib.oracle_trace_pixel(self.handle, pass_idx, seed, px, py, eye.ctypes.data, C.byref(ne),
+                                         light.ctypes.data, C.byref(nl), I.ctypes.data, splats.ctypes.data, max_splats,
+                                         C.byref(ns))
+        assert st == 0
+        return eye[:ne.value], light[:nl.value], I, splats[:min(ns.value, max_splats)]
+
+    def intersect_batch(self, rays):
+        rays = np.ascontiguousarray(rays, capi.RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], capi.HIT_DTYPE)
+        assert self.lib.oracle_intersect_batch(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data) == 0
+        return hits
+
+    def visibility_batch(self, segs):
+        segs = np.ascontiguousarray(segs, capi.SEGMENT_DTYPE)
+        vis = np.zeros(segs.shape[0], np.uint8)
+        assert self.lib.oracle_visibility_batch(self.handle, segs.ctypes.data, segs.shape[0], vis.ctypes.data) == 0
+        return vis
+
+    def object_info(self, i):
+        invW = np.zeros(16); bs = np.zeros(16)
+        area = C.c_double(); prob = C.c_double()
+        assert self.lib.oracle_get_object_info(self.handle, i, invW.ctypes.data, C.addressof(area), C.addressof(prob),
+                                               bs.ctypes.data) == 0
+        return invW, area.value, prob.value, bs
+
+    def camera_info(self):
+        v = np.zeros(16); iv = np.zeros(16); d = C.c_double()
+        assert self.lib.oracle_get_camera_info(self.handle, v.ctypes.data, iv.ctypes.data, C.addressof(d)) == 0
+        return v, iv, d.value
+
+    def texture_sample(self, tex, uv):
+        uv = np.ascontiguousarray(uv, np.float64).reshape(-1, 2)
+        out = np.zeros((uv.shape[0], 3))
+        assert self.lib.oracle_texture_sample_batch(self.handle, tex, uv.ctypes.data, uv.shape[0], out.ctypes.data) == 0
+        return out
+
+
+def _bsdf(fn, q):
+    q = np.ascontiguousarray(q, capi.BSDF_QUERY_DTYPE)
+    r = np.zeros(q.shape[0], capi.BSDF_RESULT_DTYPE)
+    assert fn(q.ctypes.data, q.shape[0], r.ctypes.data) == 0
+    return r
+
+
+def bsdf_eval(q):
+    return _bsdf(lib().oracle_bsdf_eval_batch, q)
+
+
+def bsdf_pdf(q):
+    return _bsdf(lib().oracle_bsdf_pdf_batch, q)
+
+
+def bsdf_scatter(q):
+    return _bsdf(lib().oracle_bsdf_scatter_batch, q)
+
+
+def uniform(seed, pass_idx, pixel, stream, dim):
+    return lib().oracle_uniform(seed, pass_idx, pixel, stream, dim)
+
+
+def sample_map(which, num_strata, stratum, u1, u2):
+    out = np.zeros(3)
+    assert lib().oracle_sample_map(which, num_strata, stratum, u1, u2, out.ctypes.data) == 0
+    return out
