@@ -1,0 +1,663 @@
+// api.cpp — the C ABI of include/ubdpt.h: scene flattening, device residency, pass scheduling.
+//
+// Host-side counterpart of UBDPTRenderer::initialize / renderPass / stop
+// (uengine/ubdptrenderer.cpp:7-86) and of the constructors that derive per-object data in the
+// reference (uapp/object.cpp:5-12, uapp/emitter.cpp:3-7, uapp/mesh.cpp:3-106,
+// uengine/uscene.cpp:4-19, uengine/ucamera.cpp:3-14,67-70). Compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "render.h"
+
+using namespace ub;
+
+namespace {
+
+double nowSeconds() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// uengine/ugeometry.cpp:4-15
+double triangleArea(d3 p0, d3 p1, d3 p2) {
+    d3 AB = p1 - p0;
+    d3 AC = p2 - p0;
+    double l1 = length(AB);
+    double l2 = length(AC);
+    double c = dot(AB / l1, AC / l2);
+    double s = std::sqrt(1 - c * c);
+    return 0.5 * l1 * l2 * s;
+}
+
+d3 vpos(const ubdpt_mesh_vertex& v) { return mk3((double)v.pos[0], (double)v.pos[1], (double)v.pos[2]); }
+
+// uapp/mesh.cpp:38-86
+m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
+    double max_d = 0;
+    d3 x = vpos(verts[3 * first]);
+    d3 y = mk3(0, 0, 0), z = mk3(0, 0, 0);
+    for (uint64_t i = 3 * first; i < 3 * (first + n); i++) {
+        double d = distance(vpos(verts[i]), x);
+        if (d > max_d) { max_d = d; y = vpos(verts[i]); }
+    }
+    max_d = 0;
+    for (uint64_t i = 3 * first; i < 3 * (first + n); i++) {
+        double d = distance(vpos(verts[i]), y);
+        if (d > max_d) { max_d = d; z = vpos(verts[i]); }
+    }
+    d3 center = 0.5 * (y + z);
+    double radius = 0.5 * max_d;
+    for (uint64_t i = 3 * first; i < 3 * (first + n); i++) {
+        double d = distance(vpos(verts[i]), center);
+        if (d > radius) radius = d;
+    }
+    return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
+}
+
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_INTERSECT, K_VISIBILITY, K_NUM };
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_intersect_batch", "k_visibility_batch"};
+
+struct TimedLaunch {
+    hipEvent_t start, stop;
+    int kernel;
+    double units;
+};
+
+template <class T>
+hipError_t upload(T** dst, const std::vector<T>& src) {
+    *dst = nullptr;
+    size_t bytes = sizeof(T) * (src.empty() ? 1 : src.size());
+    hipError_t e = hipMalloc((void**)dst, bytes);
+    if (e != hipSuccess) return e;
+    if (!src.empty()) e = hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice);
+    return e;
+}
+
+}  // namespace
+
+struct ubdpt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    ubdpt_options opt{};
+    ubdpt_render_params params{};
+
+    std::vector<DObject> h_objects;
+    DObject* d_objects = nullptr;
+    int32_t* d_emitters = nullptr;
+    float* d_face_pos = nullptr;
+    FaceAttr* d_face_attr = nullptr;
+    double* d_face_prob = nullptr;
+    DTexture* d_textures = nullptr;
+    uint8_t* d_texels = nullptr;
+    BvhNode* d_nodes = nullptr;
+    Prim* d_prims = nullptr;
+    DScene S{};
+
+    uint64_t npix = 0;
+    double* d_fb = nullptr;       // planar
+    double* d_staging = nullptr;  // interleaved, npix * 3
+    uint64_t cap_paths = 0;       // path slots allocated
+    uint32_t passes_in_flight = 1;
+    PathStore E{}, L{};
+    int32_t* d_ovf = nullptr;
+    unsigned long long* d_counters = nullptr;
+
+    std::atomic<bool> stop{false};
+    std::mutex mu;
+    ubdpt_stats stats{};
+    double kernel_ms[K_NUM] = {0};
+    double kernel_units[K_NUM] = {0};
+    uint64_t kernel_launches[K_NUM] = {0};
+    std::vector<TimedLaunch> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
+    uint64_t stack_overflows = 0;
+
+    hipError_t last_hip = hipSuccess;
+
+    void beginTimed(int kernel, double units) {
+        TimedLaunch t;
+        if (!event_pool.empty()) { t.start = event_pool.back().first; t.stop = event_pool.back().second; event_pool.pop_back(); }
+        else { hipEventCreate(&t.start); hipEventCreate(&t.stop); }
+        t.kernel = kernel; t.units = units;
+        hipEventRecord(t.start, stream);
+        pending.push_back(t);
+    }
+    void endTimed() { hipEventRecord(pending.back().stop, stream); }
+    void collectTimed() {  // call after the stream is synchronised
+        for (auto& t : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+                kernel_ms[t.kernel] += ms; kernel_units[t.kernel] += t.units; kernel_launches[t.kernel]++;
+            }
+            event_pool.emplace_back(t.start, t.stop);
+        }
+        pending.clear();
+    }
+    void freeAll() {
+        hipSetDevice(device);
+        if (stream) hipStreamSynchronize(stream);
+        for (auto& t : pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+        for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+        hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
+        hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
+        hipFree(E.v); hipFree(E.object); hipFree(E.flags); hipFree(E.count);
+        hipFree(L.v); hipFree(L.object); hipFree(L.flags); hipFree(L.count);
+        hipFree(d_ovf); hipFree(d_counters);
+        if (stream) hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+#define HIPCK(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->last_hip = e_; \
+    fprintf(stderr, "ubdpt: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return UBDPT_HIP_ERROR; } } while (0)
+
+int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv) {
+    P.n = n; P.maxv = maxv;
+    HIPCK(c, hipMalloc((void**)&P.v, sizeof(double) * NUM_F * maxv * n));
+    HIPCK(c, hipMalloc((void**)&P.object, sizeof(int32_t) * maxv * n));
+    HIPCK(c, hipMalloc((void**)&P.flags, sizeof(int32_t) * maxv * n));
+    HIPCK(c, hipMalloc((void**)&P.count, sizeof(uint32_t) * n));
+    return UBDPT_SUCCESS;
+}
+
+int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
+    std::vector<int32_t> emitters;
+    std::vector<float> face_pos(9 * sd->num_faces);
+    std::vector<FaceAttr> face_attr(sd->num_faces);
+    std::vector<double> face_prob(sd->num_faces, 0.0);
+    std::vector<DTexture> textures(sd->num_textures);
+    std::vector<Prim> prims;
+
+    for (uint32_t t = 0; t < sd->num_textures; t++) {
+        const ubdpt_texture& in = sd->textures[t];
+        DTexture& tx = textures[t];
+        tx.kind = in.kind; tx.width = in.width; tx.height = in.height; tx.pad = 0;
+        tx.color = mk3(in.color[0], in.color[1], in.color[2]);
+        tx.texel_offset = in.texel_offset;
+        if (in.kind == UBDPT_TEX_IMAGE) {
+            uint64_t n = (uint64_t)in.width * in.height;
+            if (n == 0 || in.texel_offset + 4 * n > sd->num_texel_bytes || !sd->texels) return UBDPT_INVALID_SCENE;
+        } else if (in.kind != UBDPT_TEX_COLOR)
+            return UBDPT_INVALID_SCENE;
+    }
+    for (uint64_t f = 0; f < sd->num_faces; f++) {
+        for (int v = 0; v < 3; v++) {
+            const ubdpt_mesh_vertex& mv = sd->vertices[3 * f + v];
+            for (int k = 0; k < 3; k++) {
+                face_pos[9 * f + 3 * v + k] = mv.pos[k];
+                face_attr[f].n[3 * v + k] = mv.normal[k];
+                face_attr[f].t[3 * v + k] = mv.tangent[k];
+            }
+            face_attr[f].uv[2 * v] = mv.uv[0];
+            face_attr[f].uv[2 * v + 1] = mv.uv[1];
+        }
+    }
+    c->h_objects.resize(sd->num_objects);
+    for (uint32_t i = 0; i < sd->num_objects; i++) {
+        const ubdpt_object& in = sd->objects[i];
+        DObject& o = c->h_objects[i];
+        memset(&o, 0, sizeof(o));
+        if (in.kind != UBDPT_MODEL_SPHERE && in.kind != UBDPT_MODEL_MESH) return UBDPT_INVALID_SCENE;
+        if (in.material > UBDPT_MAT_DIELECTRIC) return UBDPT_INVALID_SCENE;
+        if (in.texture >= sd->num_textures) return UBDPT_INVALID_SCENE;
+        o.kind = in.kind; o.material = in.material; o.texture = in.texture; o.is_emitter = in.is_emitter ? 1 : 0;
+        o.mat_a = in.mat_a; o.mat_b = in.mat_b;
+        memcpy(&o.W, in.W, sizeof(double) * 16);
+        o.invW = inverse(o.W);  // uapp/object.cpp:8
+        o.bsphere = identity4();
+        o.power = mk3(in.power[0], in.power[1], in.power[2]);
+        o.first_face = in.first_face; o.num_faces = in.num_faces;
+        o.emitter_index = -1;
+        if (o.kind == UBDPT_MODEL_MESH) {
+            if (o.num_faces == 0 || o.first_face + o.num_faces > sd->num_faces || o.num_faces >= 0xffffffffULL)
+                return UBDPT_INVALID_SCENE;
+            const ubdpt_mesh_vertex* V = sd->vertices;
+            // uapp/mesh.cpp:88-106
+            double total_area = 0;
+            for (uint64_t f = 0; f < o.num_faces; f++) {
+                uint64_t g = o.first_face + f;
+                double a = triangleArea(vpos(V[3 * g]), vpos(V[3 * g + 1]), vpos(V[3 * g + 2]));
+                face_prob[g] = a;
+                total_area += a;
+            }
+            for (uint64_t f = 0; f < o.num_faces; f++) face_prob[o.first_face + f] = face_prob[o.first_face + f] / total_area;
+            o.bsphere = boundingSphere(V, o.first_face, o.num_faces);
+            for (uint64_t f = 0; f < o.num_faces; f++) {
+                Prim p;
+                memcpy(p.p, &face_pos[9 * (o.first_face + f)], sizeof(float) * 9);
+                p.object = i; p.face = (uint32_t)f; p.pad = 0;
+                prims.push_back(p);
+            }
+        } else {
+            Prim p;
+            memset(&p, 0, sizeof(p));
+            p.object = i; p.face = kSphereFace;
+            prims.push_back(p);
+        }
+        if (o.is_emitter) {
+            o.emitter_index = (int32_t)emitters.size();
+            emitters.push_back((int32_t)i);
+            if (o.kind == UBDPT_MODEL_SPHERE) {  // uapp/implicitsphere.cpp:25-30
+                double R = length(mul_xyz(o.W, mk3(1, 0, 0), 0.0));
+                o.area = 4.0 * M_PI * R * R;
+            } else {  // uapp/mesh.cpp:191-204
+                double A = 0;
+                const ubdpt_mesh_vertex* V = sd->vertices;
+                for (uint64_t f = 0; f < o.num_faces; f++) {
+                    uint64_t g = o.first_face + f;
+                    A += triangleArea(mul_xyz(o.W, vpos(V[3 * g]), 1.0), mul_xyz(o.W, vpos(V[3 * g + 1]), 1.0),
+                                      mul_xyz(o.W, vpos(V[3 * g + 2]), 1.0));
+                }
+                o.area = A;
+            }
+        }
+    }
+    // uengine/uscene.cpp:4-19
+    {
+        double total = 0;
+        for (int32_t e : emitters) { d3 P = c->h_objects[e].power; total += (P.x + P.y + P.z) / c->h_objects[e].area; }
+        for (int32_t e : emitters) {
+            d3 P = c->h_objects[e].power;
+            c->h_objects[e].prob = (P.x + P.y + P.z) / (total * c->h_objects[e].area);
+        }
+    }
+
+    HIPCK(c, upload(&c->d_objects, c->h_objects));
+    HIPCK(c, upload(&c->d_emitters, emitters));
+    HIPCK(c, upload(&c->d_face_pos, face_pos));
+    HIPCK(c, upload(&c->d_face_attr, face_attr));
+    HIPCK(c, upload(&c->d_face_prob, face_prob));
+    HIPCK(c, upload(&c->d_textures, textures));
+    {
+        std::vector<uint8_t> tex(sd->texels, sd->texels + (sd->texels ? sd->num_texel_bytes : 0));
+        HIPCK(c, upload(&c->d_texels, tex));
+    }
+    Prim* d_unsorted = nullptr;
+    HIPCK(c, upload(&d_unsorted, prims));
+    BvhBuildResult br;
+    hipError_t be = buildLbvh(c->d_objects, d_unsorted, (uint32_t)prims.size(), c->stream, &br);
+    hipFree(d_unsorted);
+    HIPCK(c, be);
+    c->d_nodes = br.nodes;
+    c->d_prims = br.prims;
+
+    DScene& S = c->S;
+    S.objects = c->d_objects; S.emitters = c->d_emitters; S.face_pos = c->d_face_pos; S.face_attr = c->d_face_attr;
+    S.face_prob = c->d_face_prob; S.textures = c->d_textures; S.texels = c->d_texels;
+    S.nodes = c->d_nodes; S.prims = c->d_prims;
+    S.num_objects = sd->num_objects; S.num_emitters = (uint32_t)emitters.size(); S.num_prims = (uint32_t)prims.size();
+    S.accel = c->opt.accel; S.num_faces = sd->num_faces;
+
+    // uengine/ucamera.cpp:3-14,67-70 and uengine/ubdptrenderer.cpp:7-33
+    const ubdpt_camera& cam = sd->camera;
+    S.V = lookAtLH(mk3(cam.pos[0], cam.pos[1], cam.pos[2]), mk3(cam.look_at[0], cam.look_at[1], cam.look_at[2]), mk3(0, 1, 0));
+    S.invV = inverse(S.V);
+    S.image_plane_ratio = cam.ratio;
+    S.image_plane_distance = 1.0 / tanf(cam.vfov / 2.0);  // float tan, as the reference
+    const ubdpt_render_params& rp = c->params;
+    S.img_res_x = (uint32_t)rp.img_res_x; S.img_res_y = (uint32_t)rp.img_res_y;
+    S.num_pixel_strata = (uint32_t)(rp.pixel_subdiv * rp.pixel_subdiv);
+    S.num_lens_strata = (uint32_t)(rp.lens_subdiv * rp.lens_subdiv);
+    S.focus_plane_distance = rp.focus_plane_distance;
+    S.lens_radius = rp.lens_size;
+    S.min_depth = (uint32_t)rp.min_depth;
+    S.max_path_vertices = c->opt.max_path_vertices;
+    S.image_plane_area = 4 * S.image_plane_ratio;
+    S.pixel_width = 2.0 * S.image_plane_ratio / (double)S.img_res_x;
+    S.pixel_height = 2.0 / (double)S.img_res_y;
+    S.lens_area = 0.0;  // never assigned in the reference (ubdptrenderer.cpp:29-30) and value-initialised (uengine.cpp:51)
+    return UBDPT_SUCCESS;
+}
+
+int fetchCounters(ubdpt_context* c) {
+    unsigned long long h[kNumCounters];
+    HIPCK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemsetAsync(c->d_counters, 0, sizeof(h), c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
+    c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
+    c->stats.bvh_nodes_visited += h[6]; c->stats.prims_tested += h[7]; c->stats.capped_subpaths += h[8];
+    c->stack_overflows += h[9];
+    return UBDPT_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ubdpt_version(void) { return 100; }
+
+const char* ubdpt_status_string(int status) {
+    switch (status) {
+    case UBDPT_SUCCESS: return "success";
+    case UBDPT_UNINITIALIZED: return "uninitialized";
+    case UBDPT_INVALID_SCENE: return "invalid scene";
+    case UBDPT_INVALID_FORMAT: return "invalid format";
+    case UBDPT_STOPPED: return "stopped";
+    case UBDPT_NO_DATA: return "no data";
+    case UBDPT_ERROR: return "error";
+    case UBDPT_INVALID_ARG: return "invalid argument";
+    case UBDPT_NO_DEVICE: return "no HIP device";
+    case UBDPT_HIP_ERROR: return "HIP runtime error";
+    }
+    return "unknown status";
+}
+
+int ubdpt_device_count(int* count) {
+    if (!count) return UBDPT_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { *count = 0; return UBDPT_NO_DEVICE; }
+    *count = n;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* params, const ubdpt_options* options,
+                 int device, ubdpt_context** out) {
+    if (!out) return UBDPT_INVALID_ARG;
+    *out = nullptr;
+    if (!scene || !params) return UBDPT_INVALID_ARG;
+    if (params->img_res_x == 0 || params->img_res_y == 0 || params->pixel_subdiv == 0 || params->lens_subdiv == 0 ||
+        params->img_res_x > 65536 || params->img_res_y > 65536)
+        return UBDPT_INVALID_ARG;
+    if ((scene->num_objects && !scene->objects) || (scene->num_faces && !scene->vertices) ||
+        (scene->num_textures && !scene->textures))
+        return UBDPT_INVALID_SCENE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return UBDPT_NO_DEVICE;
+    if (device < 0 || device >= ndev) return UBDPT_INVALID_ARG;
+
+    ubdpt_context* c = new (std::nothrow) ubdpt_context();
+    if (!c) return UBDPT_ERROR;
+    double t0 = nowSeconds();
+    c->device = device;
+    if (options) c->opt = *options;
+    if (c->opt.max_path_vertices == 0) c->opt.max_path_vertices = 32;
+    if (c->opt.max_path_vertices < 2) c->opt.max_path_vertices = 2;
+    if (c->opt.max_path_vertices > 255) c->opt.max_path_vertices = 255;
+    c->params = *params;
+    int st = UBDPT_SUCCESS;
+    do {
+        if (hipSetDevice(device) != hipSuccess) { st = UBDPT_HIP_ERROR; break; }
+        if (hipStreamCreate(&c->stream) != hipSuccess) { st = UBDPT_HIP_ERROR; break; }
+        if ((st = flattenAndUpload(c, scene)) != UBDPT_SUCCESS) break;
+        c->npix = params->img_res_x * params->img_res_y;
+        // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
+        uint64_t per_path = (uint64_t)(sizeof(double) * NUM_F + 8) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8;
+        uint32_t pif = c->opt.passes_in_flight;
+        if (pif == 0) {
+            uint64_t target = 1ull << 20;
+            pif = (uint32_t)((target + c->npix - 1) / c->npix);
+            if (pif < 1) pif = 1;
+            if (pif > 64) pif = 64;
+        }
+        while (pif > 1 && per_path * c->npix * pif > (24ull << 30)) pif--;
+        c->passes_in_flight = pif;
+        c->cap_paths = c->npix * pif;
+        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
+        ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
+        ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
+        if (st != UBDPT_SUCCESS) break;
+        ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
+        if ((st = allocStore(c, c->E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
+        if ((st = allocStore(c, c->L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
+        ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->cap_paths));
+        ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters));
+        if (st != UBDPT_SUCCESS) break;
+        ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters, c->stream));
+        ck(hipStreamSynchronize(c->stream));
+    } while (0);
+    if (st != UBDPT_SUCCESS) {
+        c->freeAll();
+        delete c;
+        return st;
+    }
+    c->stats.build_seconds = nowSeconds() - t0;
+    *out = c;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_destroy(ubdpt_context* c) {
+    if (!c) return UBDPT_INVALID_ARG;
+    c->freeAll();
+    delete c;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                        uint32_t* passes_done) {
+    if (passes_done) *passes_done = 0;
+    if (!c) return UBDPT_INVALID_ARG;
+    if (pass_stride == 0) pass_stride = 1;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    c->stop = false;  // UBDPTRenderer::renderPass resets m_stop (ubdptrenderer.cpp:37)
+    double t0 = nowSeconds();
+    bool stats = c->opt.collect_stats != 0;
+    uint32_t done = 0;
+    int status = UBDPT_SUCCESS;
+    while (done < n_passes) {
+        if (c->stop.load()) { status = UBDPT_STOPPED; break; }
+        uint32_t nb = n_passes - done;
+        if (nb > c->passes_in_flight) nb = c->passes_in_flight;
+        RenderArgs A;
+        A.S = c->S;
+        A.E = c->E; A.L = c->L;
+        A.E.n = A.L.n = c->npix * nb;
+        A.fb = c->d_fb;
+        A.first_pass = first_pass + (uint64_t)done * pass_stride;
+        A.pass_stride = pass_stride;
+        A.seed = seed;
+        A.ovf = c->d_ovf; A.ovf_stride = A.E.n;
+        A.counters = c->d_counters;
+        double units = (double)A.E.n;
+        c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
+        c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
+        c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
+        HIPCK(c, hipGetLastError());
+        done += nb;
+        // keep at most a few batches queued so that a stop request is honoured promptly
+        if ((done / c->passes_in_flight) % 4 == 0) HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->collectTimed();
+    int fc = fetchCounters(c);
+    if (fc != UBDPT_SUCCESS) return fc;
+    c->stats.passes += done;
+    c->stats.pixel_samples += (uint64_t)done * c->npix;
+    c->stats.render_seconds += nowSeconds() - t0;
+    if (passes_done) *passes_done = done;
+    if (c->stack_overflows) {
+        fprintf(stderr, "ubdpt: traversal stack overflow on %llu rays\n", (unsigned long long)c->stack_overflows);
+        return UBDPT_ERROR;
+    }
+    return status;
+}
+
+int ubdpt_request_stop(ubdpt_context* c) {
+    if (!c) return UBDPT_INVALID_ARG;
+    c->stop = true;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_read_sum_device(ubdpt_context* c, double* device_rgb) {
+    if (!c || !device_rgb) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    launchInterleave(c->d_fb, c->npix, device_rgb, c->stream);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
+    if (!c || !rgb) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    launchInterleave(c->d_fb, c->npix, c->d_staging, c->stream);
+    HIPCK(c, hipGetLastError());
+    if (!add_into) {
+        HIPCK(c, hipMemcpyAsync(rgb, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    } else {
+        std::vector<double> tmp(3 * c->npix);
+        HIPCK(c, hipMemcpyAsync(tmp.data(), c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        for (uint64_t i = 0; i < 3 * c->npix; i++) rgb[i] += tmp[i];
+    }
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_upload_sum(ubdpt_context* c, const double* rgb) {
+    if (!c) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    if (!rgb) {
+        HIPCK(c, hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
+    } else {
+        HIPCK(c, hipMemcpyAsync(c->d_staging, rgb, sizeof(double) * 3 * c->npix, hipMemcpyHostToDevice, c->stream));
+        launchDeinterleave(c->d_staging, c->npix, c->d_fb, c->stream);
+        HIPCK(c, hipGetLastError());
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits) {
+    if (!c || (n && (!rays || !hits))) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    size_t chunk = (size_t)c->cap_paths;
+    ubdpt_ray* d_rays = nullptr;
+    ubdpt_hit* d_hits = nullptr;
+    size_t m = n < chunk ? n : chunk;
+    if (n == 0) return UBDPT_SUCCESS;
+    HIPCK(c, hipMalloc((void**)&d_rays, sizeof(ubdpt_ray) * m));
+    if (hipMalloc((void**)&d_hits, sizeof(ubdpt_hit) * m) != hipSuccess) { hipFree(d_rays); return UBDPT_HIP_ERROR; }
+    int st = UBDPT_SUCCESS;
+    for (size_t off = 0; off < n && st == UBDPT_SUCCESS; off += m) {
+        size_t k = n - off < m ? n - off : m;
+        hipError_t e = hipMemcpyAsync(d_rays, rays + off, sizeof(ubdpt_ray) * k, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            c->beginTimed(K_INTERSECT, (double)k);
+            launchIntersectBatch(c->S, d_rays, k, d_hits, c->d_ovf, k, c->d_counters, c->stream);
+            c->endTimed();
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(hits + off, d_hits, sizeof(ubdpt_hit) * k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->last_hip = e; st = UBDPT_HIP_ERROR; }
+    }
+    hipFree(d_rays); hipFree(d_hits);
+    c->collectTimed();
+    if (st == UBDPT_SUCCESS) st = fetchCounters(c);
+    if (st == UBDPT_SUCCESS && c->stack_overflows) return UBDPT_ERROR;
+    return st;
+}
+
+int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n, uint8_t* visible) {
+    if (!c || (n && (!segs || !visible))) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    if (n == 0) return UBDPT_SUCCESS;
+    size_t chunk = (size_t)c->cap_paths;
+    size_t m = n < chunk ? n : chunk;
+    ubdpt_segment* d_segs = nullptr;
+    uint8_t* d_vis = nullptr;
+    HIPCK(c, hipMalloc((void**)&d_segs, sizeof(ubdpt_segment) * m));
+    if (hipMalloc((void**)&d_vis, m) != hipSuccess) { hipFree(d_segs); return UBDPT_HIP_ERROR; }
+    int st = UBDPT_SUCCESS;
+    for (size_t off = 0; off < n && st == UBDPT_SUCCESS; off += m) {
+        size_t k = n - off < m ? n - off : m;
+        hipError_t e = hipMemcpyAsync(d_segs, segs + off, sizeof(ubdpt_segment) * k, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            c->beginTimed(K_VISIBILITY, (double)k);
+            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->d_ovf, k, c->d_counters, c->stream);
+            c->endTimed();
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(visible + off, d_vis, k, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { c->last_hip = e; st = UBDPT_HIP_ERROR; }
+    }
+    hipFree(d_segs); hipFree(d_vis);
+    c->collectTimed();
+    if (st == UBDPT_SUCCESS) st = fetchCounters(c);
+    if (st == UBDPT_SUCCESS && c->stack_overflows) return UBDPT_ERROR;
+    return st;
+}
+
+static int bsdfBatch(ubdpt_context* c, int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r) {
+    if (!c || (n && (!q || !r))) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    if (n == 0) return UBDPT_SUCCESS;
+    ubdpt_bsdf_query* dq = nullptr;
+    ubdpt_bsdf_result* dr = nullptr;
+    HIPCK(c, hipMalloc((void**)&dq, sizeof(*dq) * n));
+    if (hipMalloc((void**)&dr, sizeof(*dr) * n) != hipSuccess) { hipFree(dq); return UBDPT_HIP_ERROR; }
+    hipError_t e = hipMemcpyAsync(dq, q, sizeof(*dq) * n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) { launchBsdfBatch(mode, dq, n, dr, c->stream); e = hipGetLastError(); }
+    if (e == hipSuccess) e = hipMemcpyAsync(r, dr, sizeof(*dr) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(dq); hipFree(dr);
+    if (e != hipSuccess) { c->last_hip = e; return UBDPT_HIP_ERROR; }
+    return UBDPT_SUCCESS;
+}
+int ubdpt_bsdf_eval_batch(ubdpt_context* c, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r) { return bsdfBatch(c, 0, q, n, r); }
+int ubdpt_bsdf_pdf_batch(ubdpt_context* c, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r) { return bsdfBatch(c, 1, q, n, r); }
+int ubdpt_bsdf_scatter_batch(ubdpt_context* c, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r) { return bsdfBatch(c, 2, q, n, r); }
+
+int ubdpt_get_object_info(ubdpt_context* c, uint32_t object, double invW[16], double* area, double* probability,
+                          double bounding_sphere[16]) {
+    if (!c || object >= c->h_objects.size()) return UBDPT_INVALID_ARG;
+    const DObject& o = c->h_objects[object];
+    if (invW) memcpy(invW, &o.invW, sizeof(double) * 16);
+    if (area) *area = o.area;
+    if (probability) *probability = o.prob;
+    if (bounding_sphere) memcpy(bounding_sphere, &o.bsphere, sizeof(double) * 16);
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_get_camera_info(ubdpt_context* c, double view[16], double inv_view[16], double* image_plane_distance) {
+    if (!c) return UBDPT_INVALID_ARG;
+    if (view) memcpy(view, &c->S.V, sizeof(double) * 16);
+    if (inv_view) memcpy(inv_view, &c->S.invV, sizeof(double) * 16);
+    if (image_plane_distance) *image_plane_distance = c->S.image_plane_distance;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
+    if (!c || !out) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    *out = c->stats;
+    out->num_kernel_stats = 0;
+    for (int k = 0; k < K_NUM && out->num_kernel_stats < UBDPT_MAX_KERNEL_STATS; k++) {
+        if (c->kernel_launches[k] == 0) continue;
+        ubdpt_kernel_stat& ks = out->kernels[out->num_kernel_stats++];
+        memset(&ks, 0, sizeof(ks));
+        snprintf(ks.name, sizeof(ks.name), "%s", kKernelNames[k]);
+        ks.launches = c->kernel_launches[k]; ks.ms = c->kernel_ms[k]; ks.units = c->kernel_units[k];
+    }
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_reset_stats(ubdpt_context* c) {
+    if (!c) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    double build = c->stats.build_seconds;
+    memset(&c->stats, 0, sizeof(c->stats));
+    c->stats.build_seconds = build;
+    for (int k = 0; k < K_NUM; k++) { c->kernel_ms[k] = 0; c->kernel_units[k] = 0; c->kernel_launches[k] = 0; }
+    return UBDPT_SUCCESS;
+}
+
+}  // extern "C"

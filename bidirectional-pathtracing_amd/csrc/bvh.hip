@@ -1,0 +1,273 @@
+// bvh.hip — LBVH construction on the device (gfx950).
+//
+// The reference has no acceleration structure: UScene::intersectionPoint / visibility scan every
+// object and Mesh::localIntersection every face (uengine/uscene.cpp:21-66, uapp/mesh.cpp:108-189).
+// This builds one world-space tree over all triangles and spheres:
+//   world boxes (fp64) -> 63-bit Morton codes of the box centres -> radix sort -> Karras 2012
+//   hierarchy -> level-synchronous bottom-up refit into 64-byte two-child nodes.
+// Node boxes are fp32, rounded outward and padded by 2^-20 of the scene size, so the fp64 slab test
+// in trace.h never rejects a primitive the reference's object-local fp64 test would accept
+// (local and world coordinates differ only by the rounding of W and its inverse).
+// The refit runs one launch per tree level: a node is produced only from children finished by an
+// EARLIER launch, so no intra-launch cross-workgroup visibility is ever relied on.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "render.h"
+
+namespace ub {
+
+namespace {
+
+constexpr int kB = 256;
+
+struct Box6 { double lo[3], hi[3]; };
+struct FBox { float lo[3], hi[3]; };
+
+__device__ __forceinline__ unsigned long long orderedBits(double x) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b & 0x8000000000000000ULL) ? ~b : (b | 0x8000000000000000ULL);
+}
+__device__ __forceinline__ double fromOrdered(unsigned long long b) {
+    b = (b & 0x8000000000000000ULL) ? (b & 0x7fffffffffffffffULL) : ~b;
+    return __longlong_as_double((long long)b);
+}
+
+// world-space bounds of every primitive; scene bounds by ordered-integer atomics
+__global__ void k_prim_bounds(const DObject* objects, const Prim* prims, uint32_t n, Box6* boxes,
+                              unsigned long long* scene /*[6]: lo xyz as min, hi xyz as max*/) {
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    const Prim pr = prims[i];
+    const DObject& ob = objects[pr.object];
+    Box6 b;
+    if (pr.face == kSphereFace) {
+        // W maps the unit sphere to an ellipsoid: centre W[3], half extent on axis k = |row k of the 3x3|
+        const double* c0 = &ob.W.c[0].x; const double* c1 = &ob.W.c[1].x; const double* c2 = &ob.W.c[2].x;
+        const double* c3 = &ob.W.c[3].x;
+        for (int k = 0; k < 3; k++) {
+            double h = sqrt(c0[k] * c0[k] + c1[k] * c1[k] + c2[k] * c2[k]);
+            h = h * (1.0 + 1e-12) + 1e-300;
+            b.lo[k] = c3[k] - h;
+            b.hi[k] = c3[k] + h;
+        }
+    } else {
+        for (int k = 0; k < 3; k++) { b.lo[k] = __builtin_inf(); b.hi[k] = -__builtin_inf(); }
+        for (int v = 0; v < 3; v++) {
+            d3 p = mul_xyz(ob.W, mk3((double)pr.p[3 * v], (double)pr.p[3 * v + 1], (double)pr.p[3 * v + 2]), 1.0);
+            b.lo[0] = fmin(b.lo[0], p.x); b.hi[0] = fmax(b.hi[0], p.x);
+            b.lo[1] = fmin(b.lo[1], p.y); b.hi[1] = fmax(b.hi[1], p.y);
+            b.lo[2] = fmin(b.lo[2], p.z); b.hi[2] = fmax(b.hi[2], p.z);
+        }
+    }
+    boxes[i] = b;
+    for (int k = 0; k < 3; k++) {
+        atomicMin(&scene[k], orderedBits(b.lo[k]));
+        atomicMax(&scene[3 + k], orderedBits(b.hi[k]));
+    }
+}
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {
+    x &= 0x1fffffULL;
+    x = (x | (x << 32)) & 0x1f00000000ffffULL;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffULL;
+    x = (x | (x << 8)) & 0x100f00f00f00f00fULL;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ULL;
+    x = (x | (x << 2)) & 0x1249249249249249ULL;
+    return x;
+}
+
+__global__ void k_morton(const Box6* boxes, uint32_t n, const unsigned long long* scene, unsigned long long* keys,
+                         uint32_t* idx) {
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long code = 0;
+    for (int k = 0; k < 3; k++) {
+        double lo = fromOrdered(scene[k]), hi = fromOrdered(scene[3 + k]);
+        double c = 0.5 * (boxes[i].lo[k] + boxes[i].hi[k]);
+        double ext = hi - lo;
+        double t = ext > 0 ? (c - lo) / ext : 0.0;
+        t = fmin(fmax(t, 0.0), 1.0);
+        unsigned long long q = (unsigned long long)(t * 2097151.0);
+        code |= spread21(q) << (2 - k);
+    }
+    keys[i] = code;
+    idx[i] = i;
+}
+
+// boxes to fp32, outward, padded; primitives into tree order
+__global__ void k_gather(const Prim* prims_in, const Box6* boxes, const uint32_t* idx, uint32_t n,
+                         const unsigned long long* scene, Prim* prims_out, FBox* leaf_boxes) {
+    uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n) return;
+    uint32_t src = idx[i];
+    prims_out[i] = prims_in[src];
+    double mag = 0;
+    for (int k = 0; k < 3; k++) {
+        double lo = fromOrdered(scene[k]), hi = fromOrdered(scene[3 + k]);
+        mag = fmax(mag, fmax(fabs(lo), fabs(hi)));
+    }
+    double pad = mag * (1.0 / 1048576.0) + 1e-30;
+    FBox f;
+    for (int k = 0; k < 3; k++) {
+        f.lo[k] = __double2float_rd(boxes[src].lo[k] - pad);
+        f.hi[k] = __double2float_ru(boxes[src].hi[k] + pad);
+    }
+    leaf_boxes[i] = f;
+}
+
+// Karras 2012: common-prefix length of sorted keys i and j, ties broken by index
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+__global__ void k_hierarchy(const unsigned long long* keys, int n, int32_t* child0, int32_t* child1) {
+    int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n - 1) return;
+    int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    int j = i + l * d;
+    int dnode = delta(keys, n, i, j);
+    int s = 0;
+    int t = l;
+    do {
+        t = (t + 1) / 2;
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    int gamma = i + s * d + (d < 0 ? d : 0);
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    child0[i] = (lo == gamma) ? ~gamma : gamma;
+    child1[i] = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+}
+
+// One refit level: node i is produced when both children were finished by an earlier launch.
+// ready[i] = number of the launch that produced node i (0 = not yet).
+__global__ void k_refit_level(int n_internal, const int32_t* child0, const int32_t* child1, const FBox* leaf_boxes,
+                              FBox* node_boxes, uint32_t* ready, uint32_t level, BvhNode* nodes, uint32_t* progress) {
+    int i = blockIdx.x * kB + threadIdx.x;
+    if (i >= n_internal) return;
+    if (ready[i] != 0) return;
+    int32_t c0 = child0[i], c1 = child1[i];
+    if (c0 >= 0) { uint32_t r = ready[c0]; if (r == 0 || r >= level) return; }
+    if (c1 >= 0) { uint32_t r = ready[c1]; if (r == 0 || r >= level) return; }
+    FBox b0 = c0 < 0 ? leaf_boxes[~c0] : node_boxes[c0];
+    FBox b1 = c1 < 0 ? leaf_boxes[~c1] : node_boxes[c1];
+    BvhNode nd;
+    FBox u;
+    for (int k = 0; k < 3; k++) {
+        nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k];
+        nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k];
+        u.lo[k] = fminf(b0.lo[k], b1.lo[k]);
+        u.hi[k] = fmaxf(b0.hi[k], b1.hi[k]);
+    }
+    nd.child0 = c0; nd.child1 = c1; nd.pad0 = 0; nd.pad1 = 0;
+    nodes[i] = nd;
+    node_boxes[i] = u;
+    ready[i] = level;
+    atomicAdd(progress, 1u);
+}
+
+__global__ void k_single_leaf(const FBox* leaf_boxes, BvhNode* nodes) {
+    BvhNode nd;
+    for (int k = 0; k < 3; k++) {
+        nd.lo0[k] = leaf_boxes[0].lo[k]; nd.hi0[k] = leaf_boxes[0].hi[k];
+        nd.lo1[k] = 0; nd.hi1[k] = 0;
+    }
+    nd.child0 = ~0; nd.child1 = kEmptyChild; nd.pad0 = 0; nd.pad1 = 0;
+    nodes[0] = nd;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { err = e_; goto done; } } while (0)
+
+}  // namespace
+
+hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uint32_t n, hipStream_t s,
+                     BvhBuildResult* out) {
+    hipError_t err = hipSuccess;
+    out->nodes = nullptr; out->prims = nullptr; out->num_nodes = 0;
+    for (int k = 0; k < 3; k++) { out->scene_lo[k] = 0; out->scene_hi[k] = 0; }
+    if (n == 0) return hipSuccess;
+
+    Box6* boxes = nullptr; FBox* leaf_boxes = nullptr; FBox* node_boxes = nullptr;
+    unsigned long long *scene = nullptr, *keys = nullptr, *keys_sorted = nullptr;
+    uint32_t *idx = nullptr, *idx_sorted = nullptr, *ready = nullptr, *progress = nullptr;
+    int32_t *child0 = nullptr, *child1 = nullptr;
+    void* sort_tmp = nullptr;
+    size_t sort_bytes = 0;
+    BvhNode* nodes = nullptr; Prim* prims = nullptr;
+    uint32_t n_internal = n > 1 ? n - 1 : 1;
+    unsigned g = (n + kB - 1) / kB;
+    unsigned long long scene_init[6];
+    unsigned long long h_scene[6];
+
+    CK(hipMalloc(&boxes, sizeof(Box6) * n));
+    CK(hipMalloc(&leaf_boxes, sizeof(FBox) * n));
+    CK(hipMalloc(&node_boxes, sizeof(FBox) * n_internal));
+    CK(hipMalloc(&scene, sizeof(unsigned long long) * 6));
+    CK(hipMalloc(&keys, sizeof(unsigned long long) * n));
+    CK(hipMalloc(&keys_sorted, sizeof(unsigned long long) * n));
+    CK(hipMalloc(&idx, sizeof(uint32_t) * n));
+    CK(hipMalloc(&idx_sorted, sizeof(uint32_t) * n));
+    CK(hipMalloc(&ready, sizeof(uint32_t) * n_internal));
+    CK(hipMalloc(&progress, sizeof(uint32_t)));
+    CK(hipMalloc(&child0, sizeof(int32_t) * n_internal));
+    CK(hipMalloc(&child1, sizeof(int32_t) * n_internal));
+    CK(hipMalloc(&nodes, sizeof(BvhNode) * n_internal));
+    CK(hipMalloc(&prims, sizeof(Prim) * n));
+
+    for (int k = 0; k < 3; k++) { scene_init[k] = ~0ULL; scene_init[3 + k] = 0ULL; }
+    CK(hipMemcpyAsync(scene, scene_init, sizeof(scene_init), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_prim_bounds, dim3(g), dim3(kB), 0, s, d_objects, d_prims_unsorted, n, boxes, scene);
+    hipLaunchKernelGGL(k_morton, dim3(g), dim3(kB), 0, s, boxes, n, scene, keys, idx);
+    CK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys, keys_sorted, idx, idx_sorted, (int)n, 0, 63, s));
+    CK(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 16));
+    CK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys_sorted, idx, idx_sorted, (int)n, 0, 63, s));
+    hipLaunchKernelGGL(k_gather, dim3(g), dim3(kB), 0, s, d_prims_unsorted, boxes, idx_sorted, n, scene, prims, leaf_boxes);
+    if (n == 1) {
+        hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(1), 0, s, leaf_boxes, nodes);
+    } else {
+        unsigned gi = (n_internal + kB - 1) / kB;
+        hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(kB), 0, s, keys_sorted, (int)n, child0, child1);
+        CK(hipMemsetAsync(ready, 0, sizeof(uint32_t) * n_internal, s));
+        CK(hipMemsetAsync(progress, 0, sizeof(uint32_t), s));
+        uint32_t done_nodes = 0, level = 1;
+        // tree depth is bounded by the key length plus the index tie-break bits
+        while (done_nodes < n_internal && level <= 160) {
+            for (int rep = 0; rep < 8; rep++, level++)
+                hipLaunchKernelGGL(k_refit_level, dim3(gi), dim3(kB), 0, s, (int)n_internal, child0, child1, leaf_boxes,
+                                   node_boxes, ready, level, nodes, progress);
+            CK(hipMemcpyAsync(&done_nodes, progress, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            CK(hipStreamSynchronize(s));
+        }
+        if (done_nodes < n_internal) { err = hipErrorUnknown; goto done; }
+    }
+    CK(hipMemcpyAsync(h_scene, scene, sizeof(h_scene), hipMemcpyDeviceToHost, s));
+    CK(hipStreamSynchronize(s));
+    CK(hipGetLastError());
+    for (int k = 0; k < 3; k++) {
+        unsigned long long b = h_scene[k];
+        b = (b & 0x8000000000000000ULL) ? (b & 0x7fffffffffffffffULL) : ~b;
+        double lo; memcpy(&lo, &b, 8);
+        b = h_scene[3 + k];
+        b = (b & 0x8000000000000000ULL) ? (b & 0x7fffffffffffffffULL) : ~b;
+        double hi; memcpy(&hi, &b, 8);
+        out->scene_lo[k] = (float)lo; out->scene_hi[k] = (float)hi;
+    }
+    out->nodes = nodes; out->prims = prims; out->num_nodes = n_internal;
+    nodes = nullptr; prims = nullptr;
+done:
+    hipFree(boxes); hipFree(leaf_boxes); hipFree(node_boxes); hipFree(scene); hipFree(keys); hipFree(keys_sorted);
+    hipFree(idx); hipFree(idx_sorted); hipFree(ready); hipFree(progress); hipFree(child0); hipFree(child1);
+    hipFree(sort_tmp); hipFree(nodes); hipFree(prims);
+    return err;
+}
+
+}  // namespace ub

@@ -1,0 +1,257 @@
+// paths.h — path-vertex storage in HBM and the BDPT measurement routines that read it.
+//
+// Vertex storage is a structure of arrays indexed [field][slot][path]: consecutive lanes (paths)
+// touch consecutive 8-byte words, so every vertex field access of a wave is one coalesced 512-byte
+// transaction, whatever slot the wave is working on. A vertex is UPathVertex
+// (uengine/ubdptrenderer.h:9-24) minus the two 128-byte matrices and the shared_ptrs, which are
+// replaced by the object index and the lobe id.
+#pragma once
+
+#include "bsdf.h"
+
+namespace ub {
+
+enum { F_POS = 0, F_NG = 3, F_NS = 6, F_TS = 9, F_BS = 12, F_A = 15, F_PL = 18, F_PE = 19, F_U = 20, F_V = 21, NUM_F = 22 };
+
+struct PathStore {
+    double* v;        // [NUM_F][maxv][n]
+    int32_t* object;  // [maxv][n]
+    int32_t* flags;   // [maxv][n]  bits 0..7 = lobe + 1, bit 8 = specular
+    uint32_t* count;  // [n] vertices stored
+    uint64_t n;
+    uint32_t maxv;
+
+    DEV uint64_t at(int f, uint32_t slot, uint64_t i) const { return ((uint64_t)f * maxv + slot) * n + i; }
+    DEV double ld(int f, uint32_t slot, uint64_t i) const { return v[at(f, slot, i)]; }
+    DEV void st(int f, uint32_t slot, uint64_t i, double x) const { v[at(f, slot, i)] = x; }
+    DEV d3 ld3(int f, uint32_t slot, uint64_t i) const {
+        return mk3(v[at(f, slot, i)], v[at(f + 1, slot, i)], v[at(f + 2, slot, i)]);
+    }
+    DEV void st3(int f, uint32_t slot, uint64_t i, d3 x) const {
+        v[at(f, slot, i)] = x.x; v[at(f + 1, slot, i)] = x.y; v[at(f + 2, slot, i)] = x.z;
+    }
+    DEV int32_t obj(uint32_t slot, uint64_t i) const { return object[(uint64_t)slot * n + i]; }
+    DEV int32_t flg(uint32_t slot, uint64_t i) const { return flags[(uint64_t)slot * n + i]; }
+    DEV bool specular(uint32_t slot, uint64_t i) const { return (flg(slot, i) >> 8) & 1; }
+    DEV int lobe(uint32_t slot, uint64_t i) const { return (flg(slot, i) & 0xff) - 1; }
+};
+
+// A vertex held in registers while it is being built.
+struct Vertex {
+    SurfacePoint sp;
+    d3 a;
+    bool specular;
+    double p_light_A, p_eye_A;
+};
+
+DEV void storeVertex(const PathStore& P, uint32_t slot, uint64_t i, const Vertex& x) {
+    P.st3(F_POS, slot, i, x.sp.pos); P.st3(F_NG, slot, i, x.sp.Ng); P.st3(F_NS, slot, i, x.sp.Ns);
+    P.st3(F_TS, slot, i, x.sp.Ts);   P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
+    P.st(F_PL, slot, i, x.p_light_A); P.st(F_PE, slot, i, x.p_eye_A);
+    P.st(F_U, slot, i, x.sp.tex_u);   P.st(F_V, slot, i, x.sp.tex_v);
+    P.object[(uint64_t)slot * P.n + i] = x.sp.object;
+    P.flags[(uint64_t)slot * P.n + i] = ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0);
+}
+
+// The few fields of the last stored vertex that the subpath loop keeps in registers.
+struct Tail {
+    d3 pos, Ns;
+    double p_eye_A;
+    bool specular;
+};
+
+// s0sample (uengine/ubdptrenderer.cpp:156-222). `n` = subpath.size(), `cur` = subpath.back(),
+// `prev_specular` = subpath[n-2].specular; earlier vertices are read from the store.
+DEV d3 s0sample(const DScene& S, const PathStore& E, uint64_t i, uint32_t n, const Tail& cur, bool prev_specular,
+                const Vertex& ev) {
+    if (ev.sp.object < 0) return mk3(0, 0, 0);
+    const DObject& e = S.objects[ev.sp.object];
+    if (!e.is_emitter) return mk3(0, 0, 0);
+    double w = 1.0;
+    double ratio = (e.prob / e.area) / ev.p_eye_A;
+    if (!cur.specular) w += ratio * ratio;
+    d3 edge = cur.pos - ev.sp.pos;
+    double edge_length2 = dot(edge, edge);
+    edge = edge / sqrt(edge_length2);
+    double d1 = dot(ev.sp.Ns, edge);
+    double d2 = dot(cur.Ns, -edge);
+    double G = fabs(d1 * d2) / edge_length2;
+    double p_light_psa = 1.0 / (2.0 * kPi * fabs(d1));
+    ratio *= (p_light_psa * G) / cur.p_eye_A;
+    if (!cur.specular) {
+        if (n > 1) {
+            if (!prev_specular) w += ratio * ratio;
+        } else
+            w += ratio * ratio;
+    }
+    if (n > 2)
+        for (int v = (int)n - 2; v > 0; v--) {
+            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
+            if (E.specular(v, i)) continue;
+            if (E.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    w = 1.0 / w;
+    d3 c = (e.power / e.area) * p_light_psa;
+    return w * c * ev.a;
+}
+
+// ubdptrenderer.cpp:303-320 / 493-510: frame flip for transmission, LOCAL-space offset, to world.
+DEV void finishVertex(const DObject& o, Vertex& nv, d3 next_dirT) {
+    if (next_dirT.y < 0) {
+        nv.sp.Ng = nv.sp.Ng * -1.0; nv.sp.Ns = nv.sp.Ns * -1.0;
+        nv.sp.Ts = nv.sp.Ts * -1.0; nv.sp.Bs = nv.sp.Bs * -1.0;
+    }
+    nv.sp.pos = nv.sp.pos + 0.00001 * nv.sp.Ng;
+    nv.sp.pos = transformPoint(o.W, nv.sp.pos);
+    nv.sp.Ng = transformVectorT(o.invW, nv.sp.Ng);
+    nv.sp.Ns = transformVectorT(o.invW, nv.sp.Ns);
+    nv.sp.Ts = transformVectorT(o.invW, nv.sp.Ts);
+    nv.sp.Bs = transformVectorT(o.invW, nv.sp.Bs);
+}
+
+// |d1 * d2| / len^2 with d1 = dot(edge, n_from), d2 = dot(-edge, n_to), edge = unit(to - from)
+// (the G_prev / G_next blocks of ubdptrenderer.cpp:379-395, 568-584)
+DEV double geomAbs(d3 from, d3 n_from, d3 to, d3 n_to) {
+    d3 edge = to - from;
+    double l2 = dot(edge, edge);
+    edge = edge / sqrt(l2);
+    double d1 = dot(edge, n_from);
+    double d2 = dot(-edge, n_to);
+    return fabs(d1 * d2) / l2;
+}
+
+// A stored vertex as the connection code needs it.
+struct ConnVertex {
+    d3 pos, Ng, Ns, Ts, Bs, a;
+    double p_light_A, p_eye_A, tex_u, tex_v;
+    int32_t object;
+    int lobe;
+    bool specular;
+};
+DEV void loadConn(const PathStore& P, uint32_t slot, uint64_t i, ConnVertex& c) {
+    c.pos = P.ld3(F_POS, slot, i); c.Ng = P.ld3(F_NG, slot, i); c.Ns = P.ld3(F_NS, slot, i);
+    c.Ts = P.ld3(F_TS, slot, i);   c.Bs = P.ld3(F_BS, slot, i); c.a = P.ld3(F_A, slot, i);
+    c.p_light_A = P.ld(F_PL, slot, i); c.p_eye_A = P.ld(F_PE, slot, i);
+    c.tex_u = P.ld(F_U, slot, i); c.tex_v = P.ld(F_V, slot, i);
+    c.object = P.obj(slot, i);
+    int f = P.flg(slot, i);
+    c.lobe = (f & 0xff) - 1;
+    c.specular = (f >> 8) & 1;
+}
+DEV Frame frameOf(const ConnVertex& c) { Frame f; f.Ng = c.Ng; f.Ns = c.Ns; f.Ts = c.Ts; f.Bs = c.Bs; return f; }
+
+// Projects a light vertex onto the image plane (ubdptrenderer.cpp:111-131). Returns false when the
+// projection misses the image; otherwise the pixel the sample contributes to.
+DEV bool t1Pixel(const DScene& S, d3 light_pos, d3 lens_pos, uint32_t& px, uint32_t& py) {
+    d3 rayW = light_pos - lens_pos;
+    d3 rayV = normalize(mul_xyz(S.V, rayW, 0.0));
+    double d = S.image_plane_distance / rayV.z;
+    d3 lens_posV = mul_xyz(S.V, lens_pos, 1.0);
+    d3 ipV = lens_posV + d * rayV;
+    double pu = 0.5 * ((ipV.x / S.image_plane_ratio) + 1);
+    double pv = 1.0 - 0.5 * (ipV.y + 1);
+    if (!((pu >= 0) && (pu <= 1) && (pv >= 0) && (pv <= 1))) return false;
+    px = (uint32_t)floor((double)(S.img_res_x - 1) * pu);  // the reference maps with (W-1), (H-1)
+    py = (uint32_t)floor((double)(S.img_res_y - 1) * pv);
+    return true;
+}
+
+// connectionFactor after the specular and visibility tests (ubdptrenderer.cpp:612-690).
+// lprev = light_subpath[s-2].pos (s > 1), eprev = eye_subpath[t-2].pos (t > 1).
+DEV bool connectionFactorTail(const DScene& S, const ConnVertex& vl, const ConnVertex& ve, uint32_t s, uint32_t t,
+                              d3 lprev, d3 eprev, d3& c) {
+    d3 ce = vl.pos - ve.pos;
+    double ce_length2 = dot(ce, ce);
+    ce = ce / sqrt(ce_length2);
+    double d1 = dot(ce, ve.Ng);
+    double d2 = dot(-ce, vl.Ng);
+    if ((d1 <= 0) || (d2 <= 0)) return false;
+    d1 = dot(ce, ve.Ns);
+    d2 = dot(-ce, vl.Ns);
+    double G = (d1 * d2) / ce_length2;
+    d3 fs1, fs2;
+    if (s == 1)
+        fs1 = mk3(1, 1, 1) * (1.0 / (2.0 * kPi * d2));
+    else {
+        m3 TNB = mk_m3(vl.Ts, vl.Ns, vl.Bs);
+        fs1 = bsdfEval(vl.lobe, S.objects[vl.object].mat_a, textureSample(S, S.objects[vl.object].texture, vl.tex_u, vl.tex_v),
+                       frameOf(vl), normalize(rowmul(lprev - vl.pos, TNB)), normalize(rowmul(ve.pos - vl.pos, TNB)));
+        if (fs1.x + fs1.y + fs1.z <= 0) return false;
+    }
+    if (t == 1) {
+        d3 edgeV = mul_xyz(S.V, ce, 0.0);
+        double d = S.image_plane_distance / edgeV.z;
+        double d2_image_plane = dot(-edgeV, mk3(0, 0, -1));
+        double G_image_plane = fabs(d1 * d2_image_plane) / (d * d);
+        fs2 = mk3(1, 1, 1) * ((1.0 / (S.image_plane_area)) / G_image_plane);
+    } else {
+        m3 TNB = mk_m3(ve.Ts, ve.Ns, ve.Bs);
+        fs2 = bsdfEval(ve.lobe, S.objects[ve.object].mat_a, textureSample(S, S.objects[ve.object].texture, ve.tex_u, ve.tex_v),
+                       frameOf(ve), normalize(rowmul(vl.pos - ve.pos, TNB)), normalize(rowmul(eprev - ve.pos, TNB)));
+        if (fs2.x + fs2.y + fs2.z <= 0) return false;
+    }
+    c = fs1 * fs2 * G;
+    return true;
+}
+
+// weight (ubdptrenderer.cpp:779-844) with p_sp1 (:693-735) and p_sm1 (:737-777) inlined.
+DEV double misWeight(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+                     const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev) {
+    double w = 1.0;
+    double ratio = 1.0;
+    // shared geometry of p_sp1 / p_sm1
+    d3 ce = vl.pos - ve.pos;
+    double ce_length2 = dot(ce, ce);
+    ce = ce / sqrt(ce_length2);
+    double d1 = dot(ce, ve.Ns);
+    double d2 = dot(-ce, vl.Ns);
+    double G = (d1 * d2) / ce_length2;
+    if (t > 1) {
+        // p_sp1
+        if (s == 1)
+            ratio = (1.0 / (2.0 * kPi * d2));
+        else {
+            m3 TNB = mk_m3(vl.Ts, vl.Ns, vl.Bs);
+            d3 wsT = rowmul(normalize(ve.pos - vl.pos), TNB);
+            d3 wgT = rowmul(normalize(lprev - vl.pos), TNB);
+            ratio = bsdfPdf(vl.lobe, S.objects[vl.object].mat_a, frameOf(vl), wsT, wgT);
+        }
+        ratio *= G;
+        ratio = ratio / ve.p_eye_A;
+        if (!E.specular(t - 2, i)) w += ratio * ratio;
+    }
+    if (t > 2)
+        for (int v = (int)t - 2; v > 0; v--) {
+            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
+            if (E.specular(v, i)) continue;
+            if (E.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    // p_sm1
+    double p_eye_A;
+    if (t == 1)
+        p_eye_A = (1.0 / S.image_plane_area);
+    else {
+        m3 TNB = mk_m3(ve.Ts, ve.Ns, ve.Bs);
+        d3 wsT = rowmul(normalize(vl.pos - ve.pos), TNB);
+        d3 wgT = rowmul(normalize(eprev - ve.pos), TNB);
+        p_eye_A = (bsdfPdf(ve.lobe, S.objects[ve.object].mat_a, frameOf(ve), wsT, wgT) * G);
+    }
+    ratio = (p_eye_A / vl.p_light_A);
+    if (s > 1) {
+        if (!L.specular(s - 2, i)) w += ratio * ratio;
+    } else
+        w += ratio * ratio;
+    if (s > 1)
+        for (int v = (int)s - 2; v >= 0; v--) {
+            ratio *= L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
+            if (L.specular(v, i)) continue;
+            if (v > 0)
+                if (L.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    return (1.0 / w);
+}
+
+}  // namespace ub

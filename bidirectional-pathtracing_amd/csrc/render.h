@@ -1,0 +1,46 @@
+// render.h — host-visible launch interface of the device code (render.hip, bvh.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/ubdpt.h"
+#include "paths.h"
+
+namespace ub {
+
+struct RenderArgs {
+    DScene S;
+    PathStore E, L;        // eye / light subpath vertices of the batch
+    double* fb;            // planar sum buffer: R[npix], G[npix], B[npix]
+    uint64_t first_pass, pass_stride, seed;
+    int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
+    uint64_t ovf_stride;
+    unsigned long long* counters;
+};
+
+constexpr int kNumCounters = 16;
+
+void launchEye(const RenderArgs& A, bool stats, hipStream_t s);
+void launchLight(const RenderArgs& A, bool stats, hipStream_t s);
+void launchConnect(const RenderArgs& A, bool stats, hipStream_t s);
+void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
+                          uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);
+void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
+                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);
+void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
+void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
+void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);
+
+// LBVH build (bvh.hip). Inputs are device arrays; returns hipSuccess or the failing HIP status.
+// `prims_unsorted` holds one Prim per primitive in object order; on return `prims_out` holds them in
+// tree order and `nodes_out` the tree (max(1, n-1) nodes, root = node 0).
+struct BvhBuildResult {
+    BvhNode* nodes;   // device, owned by caller after return
+    Prim* prims;      // device, owned by caller after return
+    uint32_t num_nodes;
+    float scene_lo[3], scene_hi[3];
+};
+hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uint32_t num_prims, hipStream_t s,
+                     BvhBuildResult* out);
+
+}  // namespace ub

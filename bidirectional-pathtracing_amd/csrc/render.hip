@@ -1,0 +1,554 @@
+// render.hip — the BDPT pass on the device (gfx950).
+//
+// One pixel-sample = one UBDPTRenderer::renderPixel call (uengine/ubdptrenderer.cpp:88-154): an eye
+// subpath, a light subpath, all (s,t) connections with power-heuristic MIS, the s=0 emission hits
+// and the t=1 light-tracer splats. A batch of `n_passes` passes runs concurrently (pass index is
+// part of the path id), results are added to a planar fp64 sum buffer with hardware f64 atomics.
+#include <hip/hip_runtime.h>
+
+#include "paths.h"
+#include "render.h"
+
+namespace ub {
+
+constexpr int kBlock = 256;
+
+// counters, indices into RenderArgs::counters
+enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_NUM };
+
+struct Tally {
+    uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0;
+    TraceCounters tc{0, 0};
+};
+
+DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid) {
+    Stack st;
+    st.lds = lds_base + threadIdx.x;
+    st.lds_stride = kBlock;
+    st.ovf = ovf + gid;
+    st.ovf_stride = ovf_stride;
+    st.sp = 0;
+    st.overflowed = false;
+    return st;
+}
+
+template <bool STATS>
+DEV Closest closestHit(const DScene& S, const Ray& r, Stack& st, Tally& ty) {
+    if (STATS) ty.closest++;
+    if (S.accel == 1) return closestHitLinear(S, r, STATS ? &ty.tc : nullptr);
+    return closestHitBvh(S, r, st, STATS ? &ty.tc : nullptr);
+}
+template <bool STATS>
+DEV bool visible(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty) {
+    if (STATS) ty.shadow++;
+    if (S.accel == 1) return visibleLinear(S, p0, p1, STATS ? &ty.tc : nullptr);
+    return visibleBvh(S, p0, p1, st, STATS ? &ty.tc : nullptr);
+}
+
+DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_v, uint32_t light_v) {
+    atomicAdd(&counters[C_CLOSEST], (unsigned long long)ty.closest);
+    atomicAdd(&counters[C_SHADOW], (unsigned long long)ty.shadow);
+    atomicAdd(&counters[C_CONN], (unsigned long long)ty.conn);
+    atomicAdd(&counters[C_SPLAT], (unsigned long long)ty.splat);
+    atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
+    atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    atomicAdd(&counters[C_CAPPED], (unsigned long long)ty.capped);
+    atomicAdd(&counters[C_EYE_V], (unsigned long long)eye_v);
+    atomicAdd(&counters[C_LIGHT_V], (unsigned long long)light_v);
+}
+
+// hardware f64 atomic add into the planar sum buffer
+DEV void fbAdd(double* fb, uint64_t npix, uint64_t pixel, d3 v) {
+    unsafeAtomicAdd(fb + pixel, v.x);
+    unsafeAtomicAdd(fb + npix + pixel, v.y);
+    unsafeAtomicAdd(fb + 2 * npix + pixel, v.z);
+}
+
+DEV void decodePath(const RenderArgs& A, uint64_t gid, uint64_t& pass, uint64_t& pixel, uint32_t& px, uint32_t& py) {
+    uint64_t npix = (uint64_t)A.S.img_res_x * A.S.img_res_y;
+    uint64_t pi = gid / npix;
+    pixel = gid - pi * npix;
+    pass = A.first_pass + pi * A.pass_stride;
+    py = (uint32_t)(pixel / A.S.img_res_x);
+    px = (uint32_t)(pixel - (uint64_t)py * A.S.img_res_x);
+}
+
+// Everything between "a hit was found" and "the next ray is ready" is identical for both subpaths
+// (ubdptrenderer.cpp:285-336 and 474-523).
+struct Bounce {
+    d3 fs, dirT;
+    double p_psa;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// eye subpath: computeEyeSubpath (ubdptrenderer.cpp:224-407), primary ray = :231-257
+// ---------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= A.E.n) return;
+    const DScene& S = A.S;
+    const PathStore& E = A.E;
+    uint64_t pass, pixel;
+    uint32_t px, py;
+    decodePath(A, gid, pass, pixel, px, py);
+    Rng rng{pathKey(A.seed, pass, pixel), STREAM_EYE};
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+
+    uint32_t pixel_sample = (uint32_t)(pass % S.num_pixel_strata);
+    uint32_t lens_sample = (uint32_t)(pass % S.num_lens_strata);
+
+    d3 I = mk3(0, 0, 0);
+    d2 disk = sampleUnitDiskStratified(S.num_lens_strata, lens_sample, rng(DIM_LENS_X), rng(DIM_LENS_Y));
+    d3 lens_pointV = mk3(S.lens_radius * disk.x, S.lens_radius * disk.y, 0);
+
+    Vertex lens;
+    lens.a = mk3(1.0, 1.0, 1.0);  // m_W
+    lens.sp.pos = mul_xyz(S.invV, lens_pointV, 1.0);
+    lens.sp.Ns = lens.sp.Ng = transformVector(S.invV, mk3(0, 0, 1));
+    lens.sp.Ts = transformVector(S.invV, mk3(1, 0, 0));
+    lens.sp.Bs = transformVector(S.invV, mk3(0, 1, 0));
+    lens.sp.tex_u = 0; lens.sp.tex_v = 0; lens.sp.object = -1; lens.sp.lobe = LOBE_NONE; lens.sp.face = 0;
+    lens.p_eye_A = 1.0 / S.lens_area;  // lens_area is 0 in the reference (never assigned) -> +inf
+    lens.p_light_A = 0;
+    lens.specular = false;
+    storeVertex(E, 0, gid, lens);
+    uint32_t n = 1;
+
+    d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
+    d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
+                          1.0 - ((double)py + pp.y) * S.pixel_height, S.image_plane_distance);
+    image_pointV = normalize(image_pointV);
+    d3 focus_plane_pointV = image_pointV * (S.focus_plane_distance / image_pointV.z);
+    Ray ray;
+    ray.o = lens.sp.pos;
+    ray.d = transformVector(S.invV, focus_plane_pointV - lens_pointV);
+
+    Tail cur;   // subpath.back()
+    cur.pos = lens.sp.pos; cur.Ns = lens.sp.Ns; cur.p_eye_A = lens.p_eye_A; cur.specular = false;
+    d3 prev_pos = mk3(0, 0, 0), prev_Ns = mk3(0, 0, 0);  // subpath[n-2]
+    bool prev_specular = false;
+
+    uint32_t h = 1;
+    Vertex nv;  // next_vertex
+    nv.specular = false; nv.p_light_A = 0; nv.p_eye_A = 0; nv.a = mk3(0, 0, 0);
+    Closest hit = closestHit<STATS>(S, ray, st, ty);
+    bool alive = hit.object >= 0;
+    if (alive) {
+        surfacePoint(S, ray, hit, nv.sp);
+        nv.sp.lobe = pickLobe(S.objects[nv.sp.object], rng(hitDim(h, DIM_LOBE)));
+        nv.a = lens.a;
+        nv.p_eye_A = 1.0 / S.image_plane_area;
+    }
+    while (alive) {
+        const DObject& obj = S.objects[nv.sp.object];
+        if (nv.sp.lobe == LOBE_NONE) {  // :273-283
+            nv.sp.pos = transformPoint(obj.W, nv.sp.pos);
+            nv.sp.Ns = transformVectorT(obj.invW, nv.sp.Ns);
+            I = I + s0sample(S, E, gid, n, cur, prev_specular, nv);
+            break;
+        }
+        if (n >= S.max_path_vertices) { if (STATS) ty.capped++; break; }
+        d3 lTs = nv.sp.Ts, lNs = nv.sp.Ns, lBs = nv.sp.Bs;  // local, unflipped frame of the float TNB (:287-290)
+        Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
+        d3 w = transformVector(obj.invW, -ray.d);
+        d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+        double p_psa;
+        d3 fs, dirT;
+        if (!bsdfScatter(nv.sp.lobe, obj.mat_a, tex, fr, w, rng(hitDim(h, DIM_SCATTER_1)), rng(hitDim(h, DIM_SCATTER_2)),
+                         dirT, p_psa, fs, nv.specular))
+            break;
+        finishVertex(obj, nv, dirT);
+        I = I + s0sample(S, E, gid, n, cur, prev_specular, nv);
+        storeVertex(E, n, gid, nv);
+        n++;
+        // the pushed vertex becomes curr, the old curr becomes prev
+        prev_pos = cur.pos; prev_Ns = cur.Ns; prev_specular = cur.specular;
+        cur.pos = nv.sp.pos; cur.Ns = nv.sp.Ns; cur.p_eye_A = nv.p_eye_A; cur.specular = nv.specular;
+        d3 cur_a = nv.a;
+
+        ray.o = cur.pos;
+        ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
+        uint32_t h_curr = h;
+        h++;
+        hit = closestHit<STATS>(S, ray, st, ty);
+        if (hit.object < 0) break;
+        surfacePoint(S, ray, hit, nv.sp);
+        nv.sp.lobe = pickLobe(S.objects[nv.sp.object], rng(hitDim(h, DIM_LOBE)));
+
+        double fs_sum = fs.x + fs.y + fs.z;
+        if (!(p_psa > 0) || !(fs_sum > 0)) break;
+        double q;
+        if (n < S.min_depth) q = 1.0;
+        else {
+            q = fmin(1.0, (fs_sum / 3.0) / p_psa);
+            if (rng(hitDim(h_curr, DIM_ROULETTE)) > q) break;
+        }
+        if (cur.specular) {
+            nv.a = cur_a * fs;
+            nv.p_eye_A = q * p_psa;
+            E.st(F_PL, n - 2, gid, q * p_psa);
+        } else {
+            d3 a = fs / p_psa;
+            double G_prev = geomAbs(cur.pos, cur.Ns, prev_pos, prev_Ns);
+            // the reference uses the new hit's OBJECT-LOCAL position and normal here (:389-393)
+            double G_next = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
+            nv.a = cur_a * a;
+            nv.p_eye_A = q * p_psa * G_next;
+            E.st(F_PL, n - 2, gid, q * p_psa * G_prev);
+        }
+    }
+    E.count[gid] = n;
+    if (I.x != 0 || I.y != 0 || I.z != 0) fbAdd(A.fb, npix, pixel, I);
+    if (STATS) flushTally(ty, A.counters, n, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// light subpath: computeLightSubpath (ubdptrenderer.cpp:409-594); emitter point = uapp/emitter.cpp:19-30
+// ---------------------------------------------------------------------------------------------------
+DEV void emitterRandomPoint(const DScene& S, const DObject& e, const Rng& rng, d3& pos, d3& Ng, d3& Ns, d3& Ts, d3& Bs) {
+    if (e.kind == 0) {  // uapp/implicitsphere.cpp:32-38
+        Ns = Ng = sampleUnitSphereUniform(rng(DIM_POINT_A), rng(DIM_POINT_B));
+        pos = Ng;
+        Ts = -Ns + mk3(0, 0, 1.0 / Ns.z);
+        Bs = cross(Ns, Ts);
+    } else {  // uapp/mesh.cpp:206-232: linear walk over the face probabilities
+        double r = rng(DIM_POINT_A);
+        uint64_t f = 0;
+        for (; f + 1 < e.num_faces; f++) {
+            double p = S.face_prob[e.first_face + f];
+            if (r < p) break;
+            r -= p;
+        }
+        const float* p = S.face_pos + 9 * (e.first_face + f);
+        const FaceAttr& fa = S.face_attr[e.first_face + f];
+        d3 p0 = loadP(p), p1 = loadP(p + 3), p2 = loadP(p + 6);
+        double u, v;
+        pos = sampleTriangleUniform(p0, p1, p2, rng(DIM_POINT_B), rng(DIM_POINT_C), u, v);
+        Ns = normalize((1.0 - u - v) * loadP(fa.n) + u * loadP(fa.n + 3) + v * loadP(fa.n + 6));
+        Ng = normalize(cross(p1 - p0, p2 - p0));
+        if (dot(Ns, Ng) < 0) Ng = Ng * -1.0;
+        Ts = normalize((1.0 - u - v) * loadP(fa.t) + u * loadP(fa.t + 3) + v * loadP(fa.t + 6));
+        Bs = normalize(cross(Ns, Ts));
+    }
+    pos = pos + Ng * 0.0001;
+    pos = transformPoint(e.W, pos);
+    Ng = transformVectorT(e.invW, Ng);
+    Ns = transformVectorT(e.invW, Ns);
+    Ts = transformVectorT(e.invW, Ts);
+    Bs = transformVectorT(e.invW, Bs);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= A.L.n) return;
+    const DScene& S = A.S;
+    const PathStore& L = A.L;
+    uint64_t pass, pixel;
+    uint32_t px, py;
+    decodePath(A, gid, pass, pixel, px, py);
+    Rng rng{pathKey(A.seed, pass, pixel), STREAM_LIGHT};
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    uint32_t n = 0;
+
+    if (S.num_emitters > 0) {
+        // emitter choice by cumulative probability (:413-428)
+        double p = rng(DIM_EMITTER);
+        int32_t ei = -1;
+        for (uint32_t k = 0; k < S.num_emitters; k++) {
+            int32_t e = S.emitters[k];
+            double pe = S.objects[e].prob;
+            if (p < pe) { ei = e; break; }
+            p -= pe;
+        }
+        if (ei < 0) ei = S.emitters[S.num_emitters - 1];
+        const DObject& em = S.objects[ei];
+
+        Vertex ev;
+        emitterRandomPoint(S, em, rng, ev.sp.pos, ev.sp.Ng, ev.sp.Ns, ev.sp.Ts, ev.sp.Bs);
+        ev.sp.tex_u = 0; ev.sp.tex_v = 0; ev.sp.object = ei; ev.sp.lobe = LOBE_NONE; ev.sp.face = 0;
+        ev.a = em.power;
+        ev.p_light_A = em.prob * (1.0 / em.area);
+        ev.p_eye_A = 0;  // indeterminate in the reference (:433), zero here
+        ev.specular = false;
+        storeVertex(L, 0, gid, ev);
+        n = 1;
+
+        d3 dirT = samplePosHemUniform(rng(DIM_EMIT_ANGLE), rng(DIM_EMIT_V));
+        Ray ray;
+        ray.o = ev.sp.pos;
+        ray.d = float_tnb_mul(ev.sp.Ts, ev.sp.Ns, ev.sp.Bs, dirT);  // float TNB (:448-453), not normalised
+
+        Tail cur;
+        cur.pos = ev.sp.pos; cur.Ns = ev.sp.Ns; cur.p_eye_A = 0; cur.specular = false;
+        d3 prev_pos = mk3(0, 0, 0), prev_Ns = mk3(0, 0, 0);
+
+        uint32_t h = 1;
+        Vertex nv;
+        nv.specular = false; nv.p_light_A = 0; nv.p_eye_A = 0; nv.a = mk3(0, 0, 0);
+        Closest hit = closestHit<STATS>(S, ray, st, ty);
+        bool alive = hit.object >= 0;
+        if (alive) {
+            surfacePoint(S, ray, hit, nv.sp);
+            nv.sp.lobe = pickLobe(S.objects[nv.sp.object], rng(hitDim(h, DIM_LOBE)));
+            alive = nv.sp.lobe != LOBE_NONE;
+        }
+        if (alive) {
+            // G with the hit still in object-local space (:463-472)
+            double G = geomAbs(ev.sp.pos, ev.sp.Ns, nv.sp.pos, nv.sp.Ns);
+            nv.a = ev.a;
+            nv.p_light_A = (1 / (2.0 * kPi * dirT.y)) * G;
+        }
+        while (alive) {
+            if (n >= S.max_path_vertices) { if (STATS) ty.capped++; break; }
+            const DObject& obj = S.objects[nv.sp.object];
+            d3 lTs = nv.sp.Ts, lNs = nv.sp.Ns, lBs = nv.sp.Bs;
+            Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
+            d3 w = transformVector(obj.invW, -ray.d);
+            d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+            double p_psa;
+            d3 fs, dT;
+            if (!bsdfScatter(nv.sp.lobe, obj.mat_a, tex, fr, w, rng(hitDim(h, DIM_SCATTER_1)),
+                             rng(hitDim(h, DIM_SCATTER_2)), dT, p_psa, fs, nv.specular))
+                break;
+            finishVertex(obj, nv, dT);
+            storeVertex(L, n, gid, nv);
+            n++;
+            prev_pos = cur.pos; prev_Ns = cur.Ns;
+            cur.pos = nv.sp.pos; cur.Ns = nv.sp.Ns; cur.specular = nv.specular;
+            d3 cur_a = nv.a;
+
+            ray.o = cur.pos;
+            ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dT));
+            uint32_t h_curr = h;
+            h++;
+            hit = closestHit<STATS>(S, ray, st, ty);
+            if (hit.object < 0) break;
+            surfacePoint(S, ray, hit, nv.sp);
+            nv.sp.lobe = pickLobe(S.objects[nv.sp.object], rng(hitDim(h, DIM_LOBE)));
+            if (nv.sp.lobe == LOBE_NONE) break;
+
+            double fs_sum = fs.x + fs.y + fs.z;
+            if (!(p_psa > 0) || !(fs_sum > 0)) break;
+            double q;
+            if (n < S.min_depth) q = 1.0;
+            else {
+                q = fmin(1.0, (fs_sum / 3.0) / p_psa);
+                if (rng(hitDim(h_curr, DIM_ROULETTE)) > q) break;
+            }
+            if (cur.specular) {
+                nv.a = cur_a * fs;
+                nv.p_light_A = q * 1.0;  // the light path stores q, the eye path q * p_psa (:557-558 vs :366-367)
+                L.st(F_PE, n - 2, gid, q * 1.0);
+            } else {
+                d3 a = fs / p_psa;
+                double G_prev = geomAbs(prev_pos, prev_Ns, cur.pos, cur.Ns);
+                double G_next = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);  // local-space next vertex (:578-582)
+                nv.a = cur_a * a;
+                nv.p_light_A = q * p_psa * G_next;
+                L.st(F_PE, n - 2, gid, q * p_psa * G_prev);
+            }
+        }
+    }
+    L.count[gid] = n;
+    if (STATS) flushTally(ty, A.counters, 0, n);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// connections: the (s,t) loop of renderPixel (ubdptrenderer.cpp:103-149)
+// ---------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= A.E.n) return;
+    const DScene& S = A.S;
+    const PathStore& E = A.E;
+    const PathStore& L = A.L;
+    uint64_t pass, pixel;
+    uint32_t px, py;
+    decodePath(A, gid, pass, pixel, px, py);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+    uint32_t nE = E.count[gid], nL = L.count[gid];
+    d3 I = mk3(0, 0, 0);
+    d3 lens_pos = E.ld3(F_POS, 0, gid);
+    d3 lens_a = E.ld3(F_A, 0, gid);
+    for (uint32_t s = 1; s <= nL; s++) {
+        ConnVertex vl;
+        loadConn(L, s - 1, gid, vl);
+        if (vl.specular) continue;  // every t is rejected (:604)
+        d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, gid) : mk3(0, 0, 0);
+        for (uint32_t t = 1; t <= nE; t++) {
+            uint32_t tx = 0, tyy = 0;
+            if (t == 1) {
+                if (!t1Pixel(S, vl.pos, lens_pos, tx, tyy)) continue;
+            }
+            if (E.specular(t - 1, gid)) continue;
+            ConnVertex ve;
+            loadConn(E, t - 1, gid, ve);
+            if (!visible<STATS>(S, vl.pos, ve.pos, st, ty)) continue;
+            d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, gid) : mk3(0, 0, 0);
+            d3 c;
+            if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) continue;
+            double w = misWeight(S, L, E, gid, vl, ve, s, t, lprev, eprev);
+            if (STATS) ty.conn++;
+            if (t == 1) {
+                d3 I_t1 = vl.a * lens_a * c * w;
+                if (STATS) ty.splat++;
+                fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, I_t1);
+            } else
+                I = I + vl.a * ve.a * c * w;
+        }
+    }
+    if (I.x != 0 || I.y != 0 || I.z != 0) fbAdd(A.fb, npix, pixel, I);
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// probes: batch intersection / visibility / BSDF evaluation for parity checks
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_intersect_batch(DScene S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits,
+                                                           int32_t* ovf, uint64_t ovf_stride,
+                                                           unsigned long long* counters) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid);
+    Tally ty;
+    Ray r;
+    r.o = mk3(rays[gid].origin[0], rays[gid].origin[1], rays[gid].origin[2]);
+    r.d = mk3(rays[gid].dir[0], rays[gid].dir[1], rays[gid].dir[2]);
+    Closest c = closestHit<true>(S, r, st, ty);
+    ubdpt_hit h;
+    if (c.object >= 0) {
+        SurfacePoint sp;
+        surfacePoint(S, r, c, sp);
+        h.hit = 1; h.object = c.object; h.face = c.face == kSphereFace ? -1 : (int64_t)c.face; h.d = c.d;
+        h.pos[0] = sp.pos.x; h.pos[1] = sp.pos.y; h.pos[2] = sp.pos.z;
+        h.Ng[0] = sp.Ng.x; h.Ng[1] = sp.Ng.y; h.Ng[2] = sp.Ng.z;
+        h.Ns[0] = sp.Ns.x; h.Ns[1] = sp.Ns.y; h.Ns[2] = sp.Ns.z;
+        h.Ts[0] = sp.Ts.x; h.Ts[1] = sp.Ts.y; h.Ts[2] = sp.Ts.z;
+        h.Bs[0] = sp.Bs.x; h.Bs[1] = sp.Bs.y; h.Bs[2] = sp.Bs.z;
+        h.tex_u = sp.tex_u; h.tex_v = sp.tex_v;
+    } else {
+        h.hit = 0; h.object = -1; h.face = -1; h.d = __builtin_inf();
+        for (int k = 0; k < 3; k++) h.pos[k] = h.Ng[k] = h.Ns[k] = h.Ts[k] = h.Bs[k] = 0;
+        h.tex_u = h.tex_v = 0;
+    }
+    hits[gid] = h;
+    atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
+    atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+__global__ __launch_bounds__(kBlock) void k_visibility_batch(DScene S, const ubdpt_segment* segs, size_t n,
+                                                            uint8_t* vis, int32_t* ovf, uint64_t ovf_stride,
+                                                            unsigned long long* counters) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid);
+    Tally ty;
+    d3 p0 = mk3(segs[gid].p0[0], segs[gid].p0[1], segs[gid].p0[2]);
+    d3 p1 = mk3(segs[gid].p1[0], segs[gid].p1[1], segs[gid].p1[2]);
+    vis[gid] = visible<true>(S, p0, p1, st, ty) ? 1 : 0;
+    atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
+    atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+__global__ __launch_bounds__(kBlock) void k_bsdf_batch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* out) {
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (gid >= n) return;
+    const ubdpt_bsdf_query& Q = q[gid];
+    Frame fr;
+    fr.Ng = mk3(Q.frame[0], Q.frame[1], Q.frame[2]); fr.Ns = mk3(Q.frame[3], Q.frame[4], Q.frame[5]);
+    fr.Ts = mk3(Q.frame[6], Q.frame[7], Q.frame[8]); fr.Bs = mk3(Q.frame[9], Q.frame[10], Q.frame[11]);
+    d3 tex = mk3(Q.tex[0], Q.tex[1], Q.tex[2]);
+    d3 wi = mk3(Q.wi[0], Q.wi[1], Q.wi[2]), wo = mk3(Q.wo[0], Q.wo[1], Q.wo[2]);
+    ubdpt_bsdf_result r;
+    r.f[0] = r.f[1] = r.f[2] = 0; r.pdf = 0; r.dir[0] = r.dir[1] = r.dir[2] = 0; r.ok = 0; r.specular = 0;
+    if (mode == 0) {
+        d3 f = bsdfEval(Q.lobe, Q.eta, tex, fr, wi, wo);
+        r.f[0] = f.x; r.f[1] = f.y; r.f[2] = f.z;
+    } else if (mode == 1) {
+        r.pdf = bsdfPdf(Q.lobe, Q.eta, fr, wi, wo);
+    } else {
+        d3 dir, fs;
+        double pdf;
+        bool spec = false;
+        if (bsdfScatter(Q.lobe, Q.eta, tex, fr, wi, Q.u1, Q.u2, dir, pdf, fs, spec)) {
+            r.ok = 1; r.specular = spec ? 1 : 0; r.pdf = pdf;
+            r.f[0] = fs.x; r.f[1] = fs.y; r.f[2] = fs.z;
+            r.dir[0] = dir.x; r.dir[1] = dir.y; r.dir[2] = dir.z;
+        }
+    }
+    out[gid] = r;
+}
+
+// planar device sum buffer -> interleaved [y][x][rgb] (UBuffer2D<dvec3> layout, uengine/uutils.h:37-98)
+__global__ void k_interleave(const double* fb, uint64_t npix, double* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    out[3 * i] = fb[i];
+    out[3 * i + 1] = fb[npix + i];
+    out[3 * i + 2] = fb[2 * npix + i];
+}
+__global__ void k_deinterleave(const double* in, uint64_t npix, double* fb) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    fb[i] = in[3 * i];
+    fb[npix + i] = in[3 * i + 1];
+    fb[2 * npix + i] = in[3 * i + 2];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static inline unsigned gridFor(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+void launchEye(const RenderArgs& A, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_eye<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_eye<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+}
+void launchLight(const RenderArgs& A, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_light<true>, dim3(gridFor(A.L.n)), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_light<false>, dim3(gridFor(A.L.n)), dim3(kBlock), 0, s, A);
+}
+void launchConnect(const RenderArgs& A, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_connect<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_connect<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+}
+void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
+                          uint64_t ovf_stride, unsigned long long* counters, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_intersect_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, rays, n, hits, ovf, ovf_stride, counters);
+}
+void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
+                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_visibility_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, counters);
+}
+void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_bsdf_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, mode, q, n, r);
+}
+void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_interleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, out);
+}
+void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s) {
+    hipLaunchKernelGGL(k_deinterleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, in, npix, fb);
+}
+
+}  // namespace ub

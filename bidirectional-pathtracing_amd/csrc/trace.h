@@ -1,0 +1,352 @@
+// trace.h — ray / scene intersection on the device.
+//
+// Replaces UScene::intersectionPoint and UScene::visibility (uengine/uscene.cpp:21-66), which scan
+// every object and every face. Here a ray walks a world-space LBVH (64-byte two-child nodes) with a
+// per-lane stack whose first kLdsStack entries live in LDS ([entry][lane], bank = lane, conflict
+// free) and whose rare overflow goes to a per-lane slice of HBM. Candidate primitives are tested
+// exactly as the reference tests them: in object-local space, in fp64, in the reference's operation
+// order (URay::intersectTriangle / intersectUnitSphere, uengine/ugeometry.cpp:70-114), including
+// the per-mesh bounding-sphere gate (uapp/mesh.cpp:120,167). The reference's "first object, first
+// face wins ties" rule (strict '<' in uscene.cpp:52 and mesh.cpp:128) becomes the lexicographic
+// minimum of (d, object, face), which is independent of traversal order.
+#pragma once
+
+#include "scene.h"
+
+namespace ub {
+
+#define DEV __device__ __forceinline__
+
+constexpr int kLdsStack = 12;      // stack entries per lane kept in LDS
+constexpr int kOverflowStack = 96; // further entries per lane in HBM
+
+struct Ray {
+    d3 o, d;  // URay origin (w = 1) and direction (w = 0); the direction is NOT renormalised
+};
+
+// ugeometry.cpp:70-94
+DEV bool intersectUnitSphere(d3 o, d3 dir, double& d) {
+    double a = dot(dir, dir);
+    double b = 2 * dot(o, dir);
+    double c = dot(o, o) - 1;
+    double delta = (b * b) - (4 * a * c);
+    if (delta < 0) return false;
+    double sd = sqrt(delta);
+    d = (-b - sd) / (2 * a);
+    if (d > 0) return true;
+    d = (-b + sd) / (2 * a);
+    if (d < 0) return false;
+    return true;
+}
+
+// ugeometry.cpp:96-114
+DEV bool intersectTriangle(d3 o, d3 dir, d3 p0, d3 p1, d3 p2, double& d, double& u, double& v) {
+    d3 e1 = p1 - p0;
+    d3 e2 = p2 - p0;
+    d3 m = o - p0;
+    d3 c1 = cross(dir, e2);
+    d3 c2 = cross(m, e1);
+    double a = dot(e1, c1);
+    d = dot(e2, c2) / a;
+    u = dot(m, c1) / a;
+    v = dot(dir, c2) / a;
+    return d > 0 && u >= 0 && v >= 0 && u + v <= 1;
+}
+
+// URay::transform (ugeometry.cpp:55-58)
+DEV Ray toLocal(const m4& invW, const Ray& r) {
+    Ray l;
+    l.o = mul_xyz(invW, r.o, 1.0);
+    l.d = mul_xyz(invW, r.d, 0.0);
+    return l;
+}
+
+DEV d3 loadP(const float* p) { return mk3((double)p[0], (double)p[1], (double)p[2]); }
+
+// the closest candidate so far
+struct Closest {
+    double d, u, v;
+    int32_t object;   // -1: none
+    uint32_t face;
+};
+
+struct TraceCounters {
+    uint32_t nodes, prims;
+};
+
+// Per-ray cache of the object-local ray and of the bounding-sphere gate result.
+struct LocalCache {
+    Ray l;
+    int32_t object;       // object the local ray belongs to (-1: none)
+    int32_t gate_object;  // object the gate was evaluated for
+    bool gate_ok;
+};
+
+DEV void cacheObject(const DScene& S, const Ray& r, int32_t obj, LocalCache& c) {
+    if (c.object != obj) {
+        c.l = toLocal(S.objects[obj].invW, r);
+        c.object = obj;
+    }
+}
+// rayL.transform(m_bounding_sphere).intersectUnitSphere(d)  (uapp/mesh.cpp:120,167)
+DEV bool meshGate(const DScene& S, int32_t obj, LocalCache& c) {
+    if (c.gate_object != obj) {
+        Ray g = toLocal(S.objects[obj].bsphere, c.l);
+        double d;
+        c.gate_ok = intersectUnitSphere(g.o, g.d, d);
+        c.gate_object = obj;
+    }
+    return c.gate_ok;
+}
+
+DEV bool lexLess(double d, int32_t obj, uint32_t face, const Closest& b) {
+    return d < b.d || (d == b.d && (obj < b.object || (obj == b.object && face < b.face)));
+}
+
+// Tests one primitive for the closest-hit query.
+DEV void testPrimClosest(const DScene& S, const Ray& r, const Prim& pr, LocalCache& c, Closest& best) {
+    int32_t obj = (int32_t)pr.object;
+    cacheObject(S, r, obj, c);
+    double d, u = 0, v = 0;
+    if (pr.face == kSphereFace) {
+        if (!intersectUnitSphere(c.l.o, c.l.d, d)) return;
+    } else {
+        if (!intersectTriangle(c.l.o, c.l.d, loadP(pr.p), loadP(pr.p + 3), loadP(pr.p + 6), d, u, v)) return;
+    }
+    if (!lexLess(d, obj, pr.face, best)) return;
+    if (pr.face != kSphereFace && !meshGate(S, obj, c)) return;
+    best.d = d; best.u = u; best.v = v; best.object = obj; best.face = pr.face;
+}
+
+// Tests one primitive for the visibility query: does it block (0 < d < dist)?
+DEV bool testPrimBlocks(const DScene& S, const Ray& r, const Prim& pr, LocalCache& c, double dist) {
+    int32_t obj = (int32_t)pr.object;
+    cacheObject(S, r, obj, c);
+    double d, u, v;
+    if (pr.face == kSphereFace) {
+        if (!intersectUnitSphere(c.l.o, c.l.d, d)) return false;
+    } else {
+        if (!intersectTriangle(c.l.o, c.l.d, loadP(pr.p), loadP(pr.p + 3), loadP(pr.p + 6), d, u, v)) return false;
+    }
+    if (!((d < dist) && (d > 0))) return false;
+    if (pr.face != kSphereFace && !meshGate(S, obj, c)) return false;
+    return true;
+}
+
+// ---- slab test against a stored fp32 box, evaluated in fp64 -------------------------------------
+// Boxes are rounded outward and padded at build time (bvh.hip), so with fp64 slabs the test is
+// conservative for every ray parameter the fp64 primitive tests can accept.
+DEV bool slab(const float* lo, const float* hi, d3 o, d3 inv, double tmax, double& tnear) {
+    double t0 = ((double)lo[0] - o.x) * inv.x, t1 = ((double)hi[0] - o.x) * inv.x;
+    double tn = fmin(t0, t1), tf = fmax(t0, t1);
+    t0 = ((double)lo[1] - o.y) * inv.y; t1 = ((double)hi[1] - o.y) * inv.y;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    t0 = ((double)lo[2] - o.z) * inv.z; t1 = ((double)hi[2] - o.z) * inv.z;
+    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
+    tnear = tn;
+    return tn <= tf && tf >= 0.0 && tn <= tmax;
+}
+
+// Per-lane traversal stack: LDS for the first kLdsStack entries, HBM beyond.
+struct Stack {
+    int32_t* lds;       // &lds_stack[0][lane_in_block], stride = blockDim.x
+    int32_t* ovf;       // &overflow[0][global_lane], stride = ovf_stride
+    uint32_t lds_stride;
+    uint64_t ovf_stride;
+    int sp;
+    bool overflowed;
+    DEV void push(int32_t v) {
+        if (sp < kLdsStack) lds[sp * lds_stride] = v;
+        else if (sp < kLdsStack + kOverflowStack) ovf[(uint64_t)(sp - kLdsStack) * ovf_stride] = v;
+        else { overflowed = true; return; }
+        sp++;
+    }
+    DEV int32_t pop() {
+        sp--;
+        return sp < kLdsStack ? lds[sp * lds_stride] : ovf[(uint64_t)(sp - kLdsStack) * ovf_stride];
+    }
+};
+
+DEV d3 invDir(d3 d) { return mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+
+// UScene::intersectionPoint through the LBVH. Returns the lexicographically smallest (d, object, face).
+DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack st, TraceCounters* tc) {
+    Closest best;
+    best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
+    if (S.num_prims == 0) return best;
+    LocalCache c;
+    c.object = -1; c.gate_object = -1; c.gate_ok = false;
+    d3 inv = invDir(r.d);
+    st.sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        const BvhNode nd = S.nodes[node];
+        if (tc) tc->nodes++;
+        double tn0, tn1;
+        bool h0 = nd.child0 != kEmptyChild && slab(nd.lo0, nd.hi0, r.o, inv, best.d, tn0);
+        bool h1 = nd.child1 != kEmptyChild && slab(nd.lo1, nd.hi1, r.o, inv, best.d, tn1);
+        int32_t c0 = nd.child0, c1 = nd.child1;
+        if (h0 && c0 < 0) {
+            if (tc) tc->prims++;
+            testPrimClosest(S, r, S.prims[~c0], c, best);
+            h0 = false;
+        }
+        if (h1 && c1 < 0) {
+            if (tc) tc->prims++;
+            testPrimClosest(S, r, S.prims[~c1], c, best);
+            h1 = false;
+        }
+        if (h0 && h1) {
+            if (tn1 < tn0) { int32_t t = c0; c0 = c1; c1 = t; }
+            st.push(c1);
+            node = c0;
+        } else if (h0) node = c0;
+        else if (h1) node = c1;
+        else {
+            if (st.sp == 0) break;
+            node = st.pop();
+        }
+    }
+    return best;
+}
+
+// UScene::visibility through the LBVH: true when nothing blocks p0 -> p1.
+DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters* tc) {
+    double dist = length(p1 - p0);
+    Ray r;
+    r.o = p0;
+    r.d = (p1 - p0) / dist;
+    if (S.num_prims == 0) return true;
+    LocalCache c;
+    c.object = -1; c.gate_object = -1; c.gate_ok = false;
+    d3 inv = invDir(r.d);
+    st.sp = 0;
+    int32_t node = 0;
+    for (;;) {
+        const BvhNode nd = S.nodes[node];
+        if (tc) tc->nodes++;
+        double tn0, tn1;
+        bool h0 = nd.child0 != kEmptyChild && slab(nd.lo0, nd.hi0, r.o, inv, dist, tn0);
+        bool h1 = nd.child1 != kEmptyChild && slab(nd.lo1, nd.hi1, r.o, inv, dist, tn1);
+        int32_t c0 = nd.child0, c1 = nd.child1;
+        if (h0 && c0 < 0) {
+            if (tc) tc->prims++;
+            if (testPrimBlocks(S, r, S.prims[~c0], c, dist)) return false;
+            h0 = false;
+        }
+        if (h1 && c1 < 0) {
+            if (tc) tc->prims++;
+            if (testPrimBlocks(S, r, S.prims[~c1], c, dist)) return false;
+            h1 = false;
+        }
+        if (h0 && h1) { st.push(c1); node = c0; }
+        else if (h0) node = c0;
+        else if (h1) node = c1;
+        else {
+            if (st.sp == 0) break;
+            node = st.pop();
+        }
+    }
+    return true;
+}
+
+// ---- linear-scan accelerator: the reference's own loops, for cross-checking the tree --------------
+DEV Closest closestHitLinear(const DScene& S, const Ray& r, TraceCounters* tc) {
+    Closest best;
+    best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
+    for (uint32_t o = 0; o < S.num_objects; o++) {
+        const DObject& ob = S.objects[o];
+        Ray l = toLocal(ob.invW, r);
+        double d, u, v;
+        if (ob.kind == 0) {  // implicit sphere, uapp/implicitsphere.cpp:3-6
+            if (tc) tc->prims++;
+            if (intersectUnitSphere(l.o, l.d, d) && d < best.d) {
+                best.d = d; best.u = 0; best.v = 0; best.object = (int32_t)o; best.face = kSphereFace;
+            }
+        } else {  // uapp/mesh.cpp:108-142
+            Ray g = toLocal(ob.bsphere, l);
+            if (!intersectUnitSphere(g.o, g.d, d)) continue;
+            double cd = __builtin_inf(), cu = 0, cv = 0;
+            uint32_t cf = 0;
+            bool hit = false;
+            for (uint64_t f = 0; f < ob.num_faces; f++) {
+                const float* p = S.face_pos + 9 * (ob.first_face + f);
+                if (tc) tc->prims++;
+                if (intersectTriangle(l.o, l.d, loadP(p), loadP(p + 3), loadP(p + 6), d, u, v) && d < cd) {
+                    cd = d; cu = u; cv = v; cf = (uint32_t)f; hit = true;
+                }
+            }
+            if (hit && cd < best.d) {
+                best.d = cd; best.u = cu; best.v = cv; best.object = (int32_t)o; best.face = cf;
+            }
+        }
+    }
+    return best;
+}
+
+DEV bool visibleLinear(const DScene& S, d3 p0, d3 p1, TraceCounters* tc) {
+    double dist = length(p1 - p0);
+    Ray r;
+    r.o = p0;
+    r.d = (p1 - p0) / dist;
+    for (uint32_t o = 0; o < S.num_objects; o++) {
+        const DObject& ob = S.objects[o];
+        Ray l = toLocal(ob.invW, r);
+        double d, u, v;
+        if (ob.kind == 0) {
+            if (tc) tc->prims++;
+            if (intersectUnitSphere(l.o, l.d, d) && (d < dist) && (d > 0)) return false;
+        } else {  // uapp/mesh.cpp:161-189
+            Ray g = toLocal(ob.bsphere, l);
+            if (!intersectUnitSphere(g.o, g.d, d)) continue;
+            double md = __builtin_inf();
+            bool hit = false;
+            for (uint64_t f = 0; f < ob.num_faces; f++) {
+                const float* p = S.face_pos + 9 * (ob.first_face + f);
+                if (tc) tc->prims++;
+                if (intersectTriangle(l.o, l.d, loadP(p), loadP(p + 3), loadP(p + 6), d, u, v) && d < md) {
+                    md = d; hit = true;
+                }
+            }
+            if (hit && (md < dist) && (md > 0)) return false;
+        }
+    }
+    return true;
+}
+
+// ---- surface point of the winning candidate, object-local space ------------------------------------
+struct SurfacePoint {  // USurfacePoint (uengine/uutils.h:22-35) without the matrices
+    d3 pos, Ng, Ns, Ts, Bs;
+    double tex_u, tex_v;
+    int32_t object;
+    int32_t lobe;
+    uint32_t face;
+};
+
+DEV void surfacePoint(const DScene& S, const Ray& r, const Closest& h, SurfacePoint& sp) {
+    const DObject& ob = S.objects[h.object];
+    Ray l = toLocal(ob.invW, r);
+    sp.object = h.object;
+    sp.face = h.face;
+    sp.pos = l.o + h.d * l.d;
+    if (h.face == kSphereFace) {  // uapp/implicitsphere.cpp:8-15
+        sp.tex_u = 0; sp.tex_v = 0;
+        sp.Ns = sp.Ng = normalize(sp.pos);
+        sp.Ts = normalize(-sp.Ns + mk3(0, 0, 1.0 / sp.Ns.z));
+        sp.Bs = normalize(cross(sp.Ns, sp.Ts));
+    } else {  // uapp/mesh.cpp:144-156
+        const float* p = S.face_pos + 9 * (ob.first_face + h.face);
+        const FaceAttr& fa = S.face_attr[ob.first_face + h.face];
+        double w0 = 1.0 - h.u - h.v;
+        sp.tex_u = w0 * (double)fa.uv[0] + h.u * (double)fa.uv[2] + h.v * (double)fa.uv[4];
+        sp.tex_v = w0 * (double)fa.uv[1] + h.u * (double)fa.uv[3] + h.v * (double)fa.uv[5];
+        sp.Ns = normalize(w0 * loadP(fa.n) + h.u * loadP(fa.n + 3) + h.v * loadP(fa.n + 6));
+        d3 p0 = loadP(p);
+        sp.Ng = normalize(cross(loadP(p + 3) - p0, loadP(p + 6) - p0));
+        if (dot(sp.Ns, sp.Ng) < 0) sp.Ng = sp.Ng * -1.0;
+        sp.Ts = normalize(w0 * loadP(fa.t) + h.u * loadP(fa.t + 3) + h.v * loadP(fa.t + 6));
+        sp.Bs = normalize(cross(sp.Ns, sp.Ts));
+    }
+}
+
+}  // namespace ub

@@ -1,0 +1,260 @@
+"""Parity of the HIP backend (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: hit / object / face index, visibility bits and every derived scene quantity bit-exact;
+d, positions and normals bit-exact as well (fp64, same operation order, no FMA contraction);
+images: the same counter-based random numbers drive both sides, so pixels agree to rounding noise
+except for the few paths whose device sin/cos differ from glibc in the last bit and therefore branch
+differently; the tolerance is stated in each test.
+"""
+import numpy as np
+import pytest
+
+from util import bsdf_queries, capi, ray_batch, rel_mse, scenes, segment_batch
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+def small_mesh_scene():
+    return scenes.mesh_scene(6000, seed=3, ratio=1.0)
+
+
+SCENES = {
+    "C1": scenes.cornell_c1,
+    "C2": scenes.cornell_c2,
+    "tiny": scenes.tiny_scene,
+    "mesh6k": small_mesh_scene,
+}
+
+
+@pytest.fixture(scope="module")
+def oracle_mod():
+    import oracle_py
+    return oracle_py
+
+
+def make_pair(oracle_mod, name, w=64, h=64, accel=0, stats=0, maxv=32, pif=0):
+    scene = SCENES[name]()
+    scene.desc.camera.ratio = w / h
+    params = scenes.make_params(w, h)
+    opt = capi.Options()
+    opt.accel = accel
+    opt.collect_stats = stats
+    opt.max_path_vertices = maxv
+    opt.passes_in_flight = pif
+    ctx = capi.Context(scene, params, opt)
+    orc = oracle_mod.Oracle(scene, params, maxv)
+    return scene, ctx, orc
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_flattening_matches_oracle_bitwise(oracle_mod, name):
+    scene, ctx, orc = make_pair(oracle_mod, name)
+    for i in range(scene.n_objects):
+        a, b = ctx.object_info(i), orc.object_info(i)
+        assert np.array_equal(a[0], b[0]), f"invW of object {i}"
+        assert a[1] == b[1] and a[2] == b[2], f"area/probability of object {i}"
+        assert np.array_equal(a[3], b[3]), f"bounding sphere of object {i}"
+    ca, cb = ctx.camera_info(), orc.camera_info()
+    assert np.array_equal(ca[0], cb[0]) and np.array_equal(ca[1], cb[1]) and ca[2] == cb[2]
+    ctx.close()
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("name", list(SCENES))
+def test_intersection_bit_exact(oracle_mod, name, accel):
+    scene, ctx, orc = make_pair(oracle_mod, name, accel=accel)
+    n = 1 << 16 if name != "mesh6k" else 1 << 14
+    rays = ray_batch(n, seed=42)
+    got = ctx.intersect_batch(rays)
+    ref = orc.intersect_batch(rays)
+    assert np.array_equal(got["hit"], ref["hit"])
+    assert np.array_equal(got["object"], ref["object"])
+    assert np.array_equal(got["face"], ref["face"])
+    hit = ref["hit"] == 1
+    assert hit.sum() > n // 2
+    # bit-exact: compare the raw bytes of every double field of the hits (NaN frames on sphere equators included)
+    for f in ("d", "pos", "Ng", "Ns", "Ts", "Bs", "tex_u", "tex_v"):
+        assert np.array_equal(got[f][hit].view(np.uint64), ref[f][hit].view(np.uint64)), f
+    ctx.close()
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("name", list(SCENES))
+def test_visibility_bit_exact(oracle_mod, name, accel):
+    scene, ctx, orc = make_pair(oracle_mod, name, accel=accel)
+    n = 1 << 16 if name != "mesh6k" else 1 << 14
+    segs = segment_batch(n, seed=43)
+    got = ctx.visibility_batch(segs)
+    ref = orc.visibility_batch(segs)
+    assert np.array_equal(got, ref)
+    assert 0 < ref.sum() < n
+    ctx.close()
+
+
+def test_intersection_edge_cases(oracle_mod):
+    """Rays through shared edges / vertices of the quads, grazing sphere tangents, origins on surfaces,
+    axis-parallel directions (zero direction components) and rays that start outside pointing away."""
+    scene, ctx, orc = make_pair(oracle_mod, "C1")
+    rays = []
+    for x in (-1.0, -0.5, 0.0, 0.25, 1.0):          # towards the floor diagonal / edges / corners
+        for z in (-1.0, 0.0, 1.0):
+            rays.append(((0.0, 0.5, 0.0), (x, -1.5, z)))
+            rays.append(((x, 0.0, z), (0.0, -1.0, 0.0)))   # axis parallel, may start on a wall plane
+            rays.append(((x, 0.0, z), (0.0, 0.0, 1.0)))
+    c = np.array((-0.4, -0.65, 0.3)); r = 0.35
+    for k in range(16):                              # tangent rays to sphere A
+        ang = 2 * np.pi * k / 16
+        p = c + r * np.array((np.cos(ang), np.sin(ang), 0.0))
+        rays.append((tuple(p - np.array((0, 0, 2.0))), (0.0, 0.0, 1.0)))
+    rays.append(((0, 0, -5), (0, 0, -1)))            # pointing away from everything
+    rays.append(((-0.4, -0.65, 0.3), (0, 1, 0)))     # from the centre of sphere A
+    rays.append(((0, -1.0, 0), (1, 0, 0)))           # travelling inside the floor plane
+    arr = np.zeros(len(rays), capi.RAY_DTYPE)
+    for i, (o, d) in enumerate(rays):
+        arr["origin"][i] = o
+        arr["dir"][i] = d
+    for accel_ctx in (ctx,):
+        got = accel_ctx.intersect_batch(arr)
+        ref = orc.intersect_batch(arr)
+        assert np.array_equal(got["hit"], ref["hit"])
+        assert np.array_equal(got["object"], ref["object"])
+        assert np.array_equal(got["face"], ref["face"])
+        hit = ref["hit"] == 1
+        assert np.array_equal(got["d"][hit].view(np.uint64), ref["d"][hit].view(np.uint64))
+    ctx.close()
+
+
+def test_empty_batches_and_bad_arguments(oracle_mod):
+    scene, ctx, orc = make_pair(oracle_mod, "C1", w=8, h=8)
+    assert ctx.intersect_batch(np.zeros(0, capi.RAY_DTYPE)).shape == (0,)
+    assert ctx.visibility_batch(np.zeros(0, capi.SEGMENT_DTYPE)).shape == (0,)
+    lib = capi.load_library()
+    assert lib.ubdpt_intersect_batch(ctx.handle, None, 5, None) == capi.INVALID_ARG
+    assert lib.ubdpt_get_object_info(ctx.handle, 10 ** 6, None, None, None, None) == capi.INVALID_ARG
+    st, done = ctx.render_passes(0, 0, SEED)
+    assert st == capi.SUCCESS and done == 0
+    assert np.all(ctx.read_sum() == 0)
+    ctx.close()
+    # a scene whose mesh range is out of bounds is rejected
+    bad = scenes.cornell_c1()
+    bad.objects[0].num_faces = 10 ** 6
+    with pytest.raises(capi.UbdptError) as e:
+        capi.Context(bad, scenes.make_params(8, 8))
+    assert e.value.status == capi.INVALID_SCENE
+
+
+def test_bsdf_parity(oracle_mod):
+    scene, ctx, orc = make_pair(oracle_mod, "C1", w=8, h=8)
+    q = bsdf_queries(20000)
+    for dev, ref in ((ctx.bsdf_eval(q), oracle_mod.bsdf_eval(q)), (ctx.bsdf_pdf(q), oracle_mod.bsdf_pdf(q))):
+        assert np.array_equal(dev["f"].view(np.uint64), ref["f"].view(np.uint64))
+        assert np.array_equal(dev["pdf"].view(np.uint64), ref["pdf"].view(np.uint64))
+    dev, ref = ctx.bsdf_scatter(q), oracle_mod.bsdf_scatter(q)
+    assert np.array_equal(dev["ok"], ref["ok"]) and np.array_equal(dev["specular"], ref["specular"])
+    assert np.array_equal(dev["pdf"].view(np.uint64), ref["pdf"].view(np.uint64))
+    assert np.array_equal(dev["f"].view(np.uint64), ref["f"].view(np.uint64))
+    # sampled directions go through sin/cos: device libm vs glibc, a few ulp
+    assert np.allclose(dev["dir"], ref["dir"], rtol=0, atol=1e-14)
+    spec = ref["specular"] == 1
+    assert np.array_equal(dev["dir"][spec].view(np.uint64), ref["dir"][spec].view(np.uint64))
+    ctx.close()
+
+
+def image_agreement(got, ref, passes):
+    """Fraction of pixels whose per-pass mean differs by more than 1e-9 (relative to max(1e-3, value))."""
+    g = got / passes; r = ref / passes
+    err = np.abs(g - r) / np.maximum(np.abs(r), 1e-3)
+    bad = np.any(err > 1e-9, axis=2)
+    return float(bad.mean()), rel_mse(g, r)
+
+
+@pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("name,passes", [("C1", 4), ("C2", 4), ("tiny", 3), ("mesh6k", 2)])
+def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel):
+    """Same seed => same paths. Tolerance: at most 2 % of the pixels may deviate by more than 1e-9
+    relative (paths that branch differently after a last-bit sin/cos difference, plus the pixels their
+    splats land on), relMSE of the whole image <= 2e-3, channel means within 0.5 %."""
+    w = h = 48
+    scene, ctx, orc = make_pair(oracle_mod, name, w=w, h=h, accel=accel, stats=1)
+    st, done = ctx.render_passes(0, passes, SEED)
+    assert st == capi.SUCCESS and done == passes
+    got = ctx.read_sum()
+    ref, cn = orc.render_passes(0, passes, SEED, num_threads=4, counters=True)
+    assert np.isfinite(got).all() == np.isfinite(ref).all()
+    fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
+    bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
+    assert bad <= 0.02, f"{bad:.4f} of pixels deviate"
+    assert rm <= 2e-3, rm
+    mg, mr = got[fin].mean(0), ref[fin].mean(0)
+    assert np.all(np.abs(mg - mr) <= 5e-3 * np.abs(mr) + 1e-12)
+    # work counters: the backend traced (almost) exactly the paths the oracle traced
+    s = ctx.stats()
+    assert s["pixel_samples"] == cn["pixel_samples"] == w * h * passes
+    for k, tol in (("closest_hit_rays", 2e-3), ("eye_vertices", 2e-3), ("light_vertices", 2e-3),
+                   ("connections", 5e-3), ("splats", 5e-3)):
+        assert abs(s[k] - cn[k]) <= tol * cn[k] + 2, (k, s[k], cn[k])
+    ctx.close()
+
+
+def test_pass_partition_is_additive(oracle_mod):
+    """Passes {0..5} in one call == passes {0,2,4} + {1,3,5} with stride 2 (the multi-GPU partition),
+    and a resumed render (upload_sum) continues the same sum."""
+    scene, ctx, orc = make_pair(oracle_mod, "C2", w=32, h=32)
+    ctx.render_passes(0, 6, SEED)
+    full = ctx.read_sum()
+    ctx.upload_sum(None)
+    ctx.render_passes(0, 3, SEED, pass_stride=2)
+    even = ctx.read_sum()
+    ctx.upload_sum(None)
+    ctx.render_passes(1, 3, SEED, pass_stride=2)
+    odd = ctx.read_sum()
+    assert np.allclose(even + odd, full, rtol=1e-12, atol=1e-12)
+    # resume: upload the even half, render the odd passes on top
+    ctx.upload_sum(even)
+    ctx.render_passes(1, 3, SEED, pass_stride=2)
+    assert np.allclose(ctx.read_sum(), full, rtol=1e-12, atol=1e-12)
+    # add_into accumulates into the caller's buffer (the adapter's use)
+    acc = np.ones_like(full)
+    ctx.read_sum(acc, add_into=True)
+    assert np.allclose(acc - 1.0, full, rtol=1e-12, atol=1e-9)
+    ctx.close()
+
+
+def test_passes_in_flight_does_not_change_the_result(oracle_mod):
+    a = make_pair(oracle_mod, "C1", w=32, h=32, pif=1)[1]
+    b = make_pair(oracle_mod, "C1", w=32, h=32, pif=5)[1]
+    a.render_passes(0, 7, SEED)
+    b.render_passes(0, 7, SEED)
+    assert np.allclose(a.read_sum(), b.read_sum(), rtol=1e-12, atol=1e-12)
+    a.close(); b.close()
+
+
+def test_path_cap_matches_oracle(oracle_mod):
+    """With a small vertex cap both sides truncate the same subpaths."""
+    scene, ctx, orc = make_pair(oracle_mod, "C2", w=32, h=32, maxv=4, stats=1)
+    ctx.render_passes(0, 4, SEED)
+    got = ctx.read_sum()
+    ref, cn = orc.render_passes(0, 4, SEED, counters=True)
+    bad, rm = image_agreement(got, ref, 4)
+    assert bad <= 0.02 and rm <= 2e-3
+    s = ctx.stats()
+    assert cn["capped_subpaths"] > 0
+    assert abs(s["capped_subpaths"] - cn["capped_subpaths"]) <= 0.01 * cn["capped_subpaths"] + 2
+    ctx.close()
+
+
+def test_stop_request_is_honoured(oracle_mod):
+    import threading
+    import time
+    scene, ctx, orc = make_pair(oracle_mod, "C1", w=256, h=256, pif=1)
+    t = threading.Timer(0.05, ctx.request_stop)
+    t.start()
+    st, done = ctx.render_passes(0, 100000, SEED)
+    t.join()
+    assert st == capi.STOPPED and 0 <= done < 100000
+    # the context stays usable and a new render call resets the stop flag (ubdptrenderer.cpp:37)
+    st, done2 = ctx.render_passes(done, 1, SEED)
+    assert st == capi.SUCCESS and done2 == 1
+    ctx.close()
