@@ -71,7 +71,9 @@ BSDF_RESULT_DTYPE = np.dtype([("f", "<f8", 3), ("pdf", "<f8"), ("dir", "<f8", 3)
 
 
 class KernelStat(C.Structure):
-    _fields_ = [("name", C.c_char * 40), ("launches", C.c_uint64), ("ms", C.c_double), ("units", C.c_double)]
+    _fields_ = [("name", C.c_char * 40), ("launches", C.c_uint64), ("ms", C.c_double), ("units", C.c_double),
+                ("closest_hit_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
+                ("prims_tested", C.c_uint64), ("vertices", C.c_uint64), ("fb_updates", C.c_uint64)]
 
 
 class Stats(C.Structure):
@@ -85,8 +87,8 @@ class Stats(C.Structure):
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("kernels", "reserved", "num_kernel_stats")}
         d["kernels"] = [
-            {"name": self.kernels[i].name.decode(), "launches": self.kernels[i].launches, "ms": self.kernels[i].ms,
-             "units": self.kernels[i].units} for i in range(self.num_kernel_stats)]
+            {k: (getattr(self.kernels[i], k).decode() if k == "name" else getattr(self.kernels[i], k))
+             for k, _ in KernelStat._fields_} for i in range(self.num_kernel_stats)]
         return d
 
 

@@ -113,6 +113,7 @@ struct ubdpt_context {
     std::atomic<bool> stop{false};
     std::mutex mu;
     ubdpt_stats stats{};
+    unsigned long long kernel_counters[K_NUM][kNumCounters] = {{0}};
     double kernel_ms[K_NUM] = {0};
     double kernel_units[K_NUM] = {0};
     uint64_t kernel_launches[K_NUM] = {0};
@@ -319,14 +320,20 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
 }
 
 int fetchCounters(ubdpt_context* c) {
-    unsigned long long h[kNumCounters];
-    HIPCK(c, hipMemcpyAsync(h, c->d_counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemsetAsync(c->d_counters, 0, sizeof(h), c->stream));
+    unsigned long long hk[K_NUM][kNumCounters];
+    HIPCK(c, hipMemcpyAsync(hk, c->d_counters, sizeof(hk), hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemsetAsync(c->d_counters, 0, sizeof(hk), c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
-    c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
-    c->stats.bvh_nodes_visited += h[6]; c->stats.prims_tested += h[7]; c->stats.capped_subpaths += h[8];
-    c->stack_overflows += h[9];
+    for (int k = 0; k < K_NUM; k++) {
+        const unsigned long long* h = hk[k];
+        for (int j = 0; j < kNumCounters; j++) c->kernel_counters[k][j] += h[j];
+        if (k <= K_CONNECT) {  // the probe kernels do not count as rendering work
+            c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
+            c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
+            c->stats.bvh_nodes_visited += h[6]; c->stats.prims_tested += h[7]; c->stats.capped_subpaths += h[8];
+        }
+        c->stack_overflows += h[9];
+    }
     return UBDPT_SUCCESS;
 }
 
@@ -410,9 +417,9 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((st = allocStore(c, c->E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
         if ((st = allocStore(c, c->L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
         ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->cap_paths));
-        ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters));
+        ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
         if (st != UBDPT_SUCCESS) break;
-        ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters, c->stream));
+        ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
         ck(hipStreamSynchronize(c->stream));
     } while (0);
     if (st != UBDPT_SUCCESS) {
@@ -459,8 +466,11 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.ovf = c->d_ovf; A.ovf_stride = A.E.n;
         A.counters = c->d_counters;
         double units = (double)A.E.n;
+        A.counters = c->d_counters + K_EYE * kNumCounters;
         c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
+        A.counters = c->d_counters + K_LIGHT * kNumCounters;
         c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
+        A.counters = c->d_counters + K_CONNECT * kNumCounters;
         c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
         HIPCK(c, hipGetLastError());
         done += nb;
@@ -548,7 +558,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
         hipError_t e = hipMemcpyAsync(d_rays, rays + off, sizeof(ubdpt_ray) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_INTERSECT, (double)k);
-            launchIntersectBatch(c->S, d_rays, k, d_hits, c->d_ovf, k, c->d_counters, c->stream);
+            launchIntersectBatch(c->S, d_rays, k, d_hits, c->d_ovf, k, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -580,7 +590,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
         hipError_t e = hipMemcpyAsync(d_segs, segs + off, sizeof(ubdpt_segment) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_VISIBILITY, (double)k);
-            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->d_ovf, k, c->d_counters, c->stream);
+            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->d_ovf, k, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -646,6 +656,9 @@ int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
         memset(&ks, 0, sizeof(ks));
         snprintf(ks.name, sizeof(ks.name), "%s", kKernelNames[k]);
         ks.launches = c->kernel_launches[k]; ks.ms = c->kernel_ms[k]; ks.units = c->kernel_units[k];
+        const unsigned long long* h = c->kernel_counters[k];
+        ks.closest_hit_rays = h[0]; ks.shadow_rays = h[1]; ks.nodes_visited = h[6]; ks.prims_tested = h[7];
+        ks.vertices = h[2] + h[3]; ks.fb_updates = h[10];
     }
     return UBDPT_SUCCESS;
 }
@@ -657,6 +670,7 @@ int ubdpt_reset_stats(ubdpt_context* c) {
     memset(&c->stats, 0, sizeof(c->stats));
     c->stats.build_seconds = build;
     for (int k = 0; k < K_NUM; k++) { c->kernel_ms[k] = 0; c->kernel_units[k] = 0; c->kernel_launches[k] = 0; }
+    memset(c->kernel_counters, 0, sizeof(c->kernel_counters));
     return UBDPT_SUCCESS;
 }
 

@@ -14,10 +14,10 @@ namespace ub {
 constexpr int kBlock = 256;
 
 // counters, indices into RenderArgs::counters
-enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_NUM };
+enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB, C_NUM };
 
 struct Tally {
-    uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0;
+    uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0, fb = 0;
     TraceCounters tc{0, 0};
 };
 
@@ -53,6 +53,7 @@ DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_
     atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
     atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
     atomicAdd(&counters[C_CAPPED], (unsigned long long)ty.capped);
+    atomicAdd(&counters[C_FB], (unsigned long long)ty.fb);
     atomicAdd(&counters[C_EYE_V], (unsigned long long)eye_v);
     atomicAdd(&counters[C_LIGHT_V], (unsigned long long)light_v);
 }
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
         }
     }
     E.count[gid] = n;
-    if (I.x != 0 || I.y != 0 || I.z != 0) fbAdd(A.fb, npix, pixel, I);
+    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, n, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -404,13 +405,13 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
             if (STATS) ty.conn++;
             if (t == 1) {
                 d3 I_t1 = vl.a * lens_a * c * w;
-                if (STATS) ty.splat++;
+                if (STATS) { ty.splat++; ty.fb++; }
                 fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, I_t1);
             } else
                 I = I + vl.a * ve.a * c * w;
         }
     }
-    if (I.x != 0 || I.y != 0 || I.z != 0) fbAdd(A.fb, npix, pixel, I);
+    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }

@@ -153,6 +153,8 @@ typedef struct ubdpt_kernel_stat {
     uint64_t launches;
     double   ms;        /* HIP-event time on the backend's own stream, summed over launches */
     double   units;     /* work items summed over launches (rays, vertices, pixel-samples ...) */
+    /* work counted inside this kernel (only with collect_stats; zero otherwise) */
+    uint64_t closest_hit_rays, shadow_rays, nodes_visited, prims_tested, vertices, fb_updates;
 } ubdpt_kernel_stat;
 
 typedef struct ubdpt_stats {
