@@ -6,6 +6,7 @@
 // uengine/uscene.cpp:4-19, uengine/ucamera.cpp:3-14,67-70). Compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -62,8 +63,10 @@ m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
     return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
 }
 
-enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_INTERSECT, K_VISIBILITY, K_NUM };
-const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_intersect_batch", "k_visibility_batch"};
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_PAIR_PROCESS, K_INTERSECT, K_VISIBILITY, K_NUM };
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_pair_process",
+                                   "k_intersect_batch", "k_visibility_batch"};
+constexpr int kLastRenderKernel = K_PAIR_PROCESS;
 
 struct TimedLaunch {
     hipEvent_t start, stop;
@@ -108,7 +111,11 @@ struct ubdpt_context {
     uint32_t passes_in_flight = 1;
     PathStore E{}, L{};
     int32_t* d_ovf = nullptr;
+    uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
     unsigned long long* d_counters = nullptr;
+    uint64_t* d_pairs = nullptr;
+    unsigned long long pair_capacity = 0;
+    unsigned long long* d_pair_count = nullptr;
 
     std::atomic<bool> stop{false};
     std::mutex mu;
@@ -151,7 +158,7 @@ struct ubdpt_context {
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         hipFree(E.v); hipFree(E.object); hipFree(E.flags); hipFree(E.count);
         hipFree(L.v); hipFree(L.object); hipFree(L.flags); hipFree(L.count);
-        hipFree(d_ovf); hipFree(d_counters);
+        hipFree(d_ovf); hipFree(d_counters); hipFree(d_pairs); hipFree(d_pair_count);
         if (stream) hipStreamDestroy(stream);
     }
 };
@@ -327,7 +334,7 @@ int fetchCounters(ubdpt_context* c) {
     for (int k = 0; k < K_NUM; k++) {
         const unsigned long long* h = hk[k];
         for (int j = 0; j < kNumCounters; j++) c->kernel_counters[k][j] += h[j];
-        if (k <= K_CONNECT) {  // the probe kernels do not count as rendering work
+        if (k <= kLastRenderKernel) {  // the probe kernels do not count as rendering work
             c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
             c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
             c->stats.bvh_nodes_visited += h[6]; c->stats.prims_tested += h[7]; c->stats.capped_subpaths += h[8];
@@ -416,7 +423,11 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
         if ((st = allocStore(c, c->E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
         if ((st = allocStore(c, c->L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
-        ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->cap_paths));
+        c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
+        ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_threads));
+        c->pair_capacity = c->cap_paths * 24;
+        ck(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * c->pair_capacity));
+        ck(hipMalloc((void**)&c->d_pair_count, sizeof(unsigned long long)));
         ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
@@ -465,13 +476,24 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.seed = seed;
         A.ovf = c->d_ovf; A.ovf_stride = A.E.n;
         A.counters = c->d_counters;
+        A.pairs = c->d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = c->d_pair_count;
         double units = (double)A.E.n;
         A.counters = c->d_counters + K_EYE * kNumCounters;
         c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
         A.counters = c->d_counters + K_LIGHT * kNumCounters;
         c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
-        A.counters = c->d_counters + K_CONNECT * kNumCounters;
-        c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
+        if (c->opt.pipeline == 1) {
+            A.counters = c->d_counters + K_CONNECT * kNumCounters;
+            c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
+        } else {
+            HIPCK(c, hipMemsetAsync(c->d_pair_count, 0, sizeof(unsigned long long), c->stream));
+            A.counters = c->d_counters + K_PAIR_ENUM * kNumCounters;
+            c->beginTimed(K_PAIR_ENUM, units); launchPairEnum(A, stats, c->stream); c->endTimed();
+            A.counters = c->d_counters + K_PAIR_PROCESS * kNumCounters;
+            unsigned blocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
+            A.ovf_stride = (uint64_t)blocks * 256 > A.E.n ? (uint64_t)blocks * 256 : A.E.n;
+            c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, blocks, stats, c->stream); c->endTimed();
+        }
         HIPCK(c, hipGetLastError());
         done += nb;
         // keep at most a few batches queued so that a stop request is honoured promptly

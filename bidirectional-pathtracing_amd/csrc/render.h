@@ -16,6 +16,9 @@ struct RenderArgs {
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
     uint64_t ovf_stride;
     unsigned long long* counters;
+    uint64_t* pairs;                  // connection queue: (path << 16) | (s << 8) | t
+    unsigned long long pair_capacity;
+    unsigned long long* pair_count;   // device counter, zeroed before every batch
 };
 
 constexpr int kNumCounters = 16;
@@ -23,6 +26,8 @@ constexpr int kNumCounters = 16;
 void launchEye(const RenderArgs& A, bool stats, hipStream_t s);
 void launchLight(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s);
+void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s);
+void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,

@@ -417,6 +417,126 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// connections, wavefront form: the (s,t) pairs of all pixel-samples of the batch are flattened into
+// one queue (wave-level prefix sum + one atomic per wave to reserve queue space), then one lane
+// evaluates one pair. Lanes no longer wait for the longest (s,t) loop in their wave.
+// ---------------------------------------------------------------------------------------------------
+DEV uint64_t packPair(uint64_t i, uint32_t s, uint32_t t) { return (i << 16) | ((uint64_t)s << 8) | t; }
+
+// inclusive prefix sum across the 64 lanes of a wave
+DEV uint32_t waveInclusiveScan(uint32_t v) {
+    int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(v, d, 64);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+
+// One connection of pixel-sample i: everything renderPixel does for one (s,t) (ubdptrenderer.cpp:106-148).
+// The geometric-normal test of connectionFactor (:622-626) runs BEFORE the shadow ray here; it only
+// removes shadow rays whose connection the reference would reject right after tracing them.
+template <bool STATS>
+DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Stack& st, Tally& ty) {
+    const DScene& S = A.S;
+    const PathStore& E = A.E;
+    const PathStore& L = A.L;
+    uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+    d3 lpos = L.ld3(F_POS, s - 1, i);
+    d3 epos = E.ld3(F_POS, t - 1, i);
+    uint32_t tx = 0, tyy = 0;
+    if (t == 1) {
+        if (!t1Pixel(S, lpos, epos, tx, tyy)) return;
+    }
+    {
+        d3 ce = lpos - epos;
+        ce = ce / sqrt(dot(ce, ce));
+        if ((dot(ce, E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, L.ld3(F_NG, s - 1, i)) <= 0)) return;
+    }
+    if (!visible<STATS>(S, lpos, epos, st, ty)) return;
+    ConnVertex vl, ve;
+    loadConn(L, s - 1, i, vl);
+    loadConn(E, t - 1, i, ve);
+    d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
+    d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
+    d3 c;
+    if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return;
+    double w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
+    if (STATS) { ty.conn++; ty.fb++; }
+    if (t == 1) {
+        if (STATS) ty.splat++;
+        fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
+    } else
+        fbAdd(A.fb, npix, i % npix, vl.a * ve.a * c * w);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    bool active = gid < A.E.n;
+    const PathStore& E = A.E;
+    const PathStore& L = A.L;
+    uint32_t nE = 0, nL = 0, cE = 0, cL = 0;
+    if (active) {
+        nE = E.count[gid]; nL = L.count[gid];
+        for (uint32_t t = 0; t < nE; t++) cE += E.specular(t, gid) ? 0u : 1u;
+        for (uint32_t s = 0; s < nL; s++) cL += L.specular(s, gid) ? 0u : 1u;
+    }
+    uint32_t cnt = cE * cL;
+    uint32_t incl = waveInclusiveScan(cnt);
+    uint32_t total = __shfl(incl, 63, 64);
+    unsigned long long base = 0;
+    if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(A.pair_count, (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    if (!cnt) return;
+    unsigned long long pos = base + (incl - cnt);
+    if (pos + cnt <= A.pair_capacity) {
+        for (uint32_t s = 1; s <= nL; s++) {
+            if (L.specular(s - 1, gid)) continue;
+            for (uint32_t t = 1; t <= nE; t++) {
+                if (E.specular(t - 1, gid)) continue;
+                A.pairs[pos++] = packPair(gid, s, t);
+            }
+        }
+    } else {
+        // queue full: this lane evaluates its own pairs (slow path, same result); the part of its
+        // reservation that lies inside the queue is filled with skip records (s == 0)
+        for (unsigned long long j = pos; j < pos + cnt && j < A.pair_capacity; j++) A.pairs[j] = 0;
+        Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+        Tally ty;
+        for (uint32_t s = 1; s <= nL; s++) {
+            if (L.specular(s - 1, gid)) continue;
+            for (uint32_t t = 1; t <= nE; t++) {
+                if (E.specular(t - 1, gid)) continue;
+                connectPair<STATS>(A, gid, s, t, st, ty);
+            }
+        }
+        if (STATS) flushTally(ty, A.counters, 0, 0);
+        if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+    }
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_process(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    unsigned long long total = *A.pair_count;
+    if (total > A.pair_capacity) total = A.pair_capacity;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    for (unsigned long long j = gid; j < total; j += nthreads) {
+        uint64_t p = A.pairs[j];
+        if (((p >> 8) & 0xff) == 0) continue;
+        connectPair<STATS>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), st, ty);
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // probes: batch intersection / visibility / BSDF evaluation for parity checks
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_intersect_batch(DScene S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits,
@@ -530,6 +650,14 @@ void launchLight(const RenderArgs& A, bool stats, hipStream_t s) {
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_connect<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_connect<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+}
+void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_enum<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+}
+void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_pair_process<true>, dim3(blocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_process<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s) {

@@ -34,7 +34,7 @@ def oracle_mod():
     return oracle_py
 
 
-def make_pair(oracle_mod, name, w=64, h=64, accel=0, stats=0, maxv=32, pif=0):
+def make_pair(oracle_mod, name, w=64, h=64, accel=0, stats=0, maxv=32, pif=0, pipeline=0):
     scene = SCENES[name]()
     scene.desc.camera.ratio = w / h
     params = scenes.make_params(w, h)
@@ -43,6 +43,7 @@ def make_pair(oracle_mod, name, w=64, h=64, accel=0, stats=0, maxv=32, pif=0):
     opt.collect_stats = stats
     opt.max_path_vertices = maxv
     opt.passes_in_flight = pif
+    opt.pipeline = pipeline
     ctx = capi.Context(scene, params, opt)
     orc = oracle_mod.Oracle(scene, params, maxv)
     return scene, ctx, orc
@@ -171,13 +172,14 @@ def image_agreement(got, ref, passes):
 
 
 @pytest.mark.parametrize("accel", [0, 1])
+@pytest.mark.parametrize("pipeline", [0, 1])
 @pytest.mark.parametrize("name,passes", [("C1", 4), ("C2", 4), ("tiny", 3), ("mesh6k", 2)])
-def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel):
+def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipeline):
     """Same seed => same paths. Tolerance: at most 2 % of the pixels may deviate by more than 1e-9
     relative (paths that branch differently after a last-bit sin/cos difference, plus the pixels their
     splats land on), relMSE of the whole image <= 2e-3, channel means within 0.5 %."""
     w = h = 48
-    scene, ctx, orc = make_pair(oracle_mod, name, w=w, h=h, accel=accel, stats=1)
+    scene, ctx, orc = make_pair(oracle_mod, name, w=w, h=h, accel=accel, stats=1, pipeline=pipeline)
     st, done = ctx.render_passes(0, passes, SEED)
     assert st == capi.SUCCESS and done == passes
     got = ctx.read_sum()
