@@ -42,21 +42,35 @@ def algorithmic_bytes(k):
             + 48.0 * k["prims_tested"] + 96.0 * k["vertices"] + 24.0 * k["fb_updates"])
 
 
-def measure_work(scene, params, device, passes, seed, accel):
+def measure_work(scene, params, device, passes, seed, accel, pipeline=0):
     """Counts the work of `passes` passes with the counting build of the kernels (deterministic)."""
     opt = capi.Options()
     opt.collect_stats = 1
     opt.accel = accel
+    opt.pipeline = pipeline
     with capi.Context(scene, params, opt, device) as ctx:
         ctx.render_passes(0, passes, seed)
         s = ctx.stats()
     ps = float(s["pixel_samples"])
     per_kernel = {}
     ev = s["eye_vertices"]; lv = s["light_vertices"]
+    # vertex records: the generation kernel writes the lens and the emitter vertex of every
+    # pixel-sample, the bounce / tail / per-path kernels the rest (split by their share of closest-hit
+    # rays); the connection stage reads every vertex once
+    writers = [k for k in s["kernels"] if k["name"] in ("k_wf_bounce", "k_wf_tail", "k_eye", "k_light")]
+    wrays = float(sum(k["closest_hit_rays"] for k in writers)) or 1.0
+    has_gen = any(k["name"] == "k_wf_gen" for k in s["kernels"])
+    rest = (ev + lv - 2 * ps) if has_gen else (ev + lv)
     for k in s["kernels"]:
         kk = dict(k)
-        if k["name"] == "k_connect":
-            kk["vertices"] = ev + lv  # read once by the connection kernel
+        if k["name"] in ("k_connect", "k_pair_process"):
+            kk["vertices"] = ev + lv
+        elif k["name"] == "k_wf_gen":
+            kk["vertices"] = 2 * ps
+        elif k["name"] in ("k_wf_bounce", "k_wf_tail", "k_eye", "k_light"):
+            kk["vertices"] = rest * k["closest_hit_rays"] / wrays
+        else:
+            kk["vertices"] = 0
         per_kernel[k["name"]] = algorithmic_bytes(kk) / ps
     return {
         "bytes_per_pixel_sample": per_kernel,
@@ -101,6 +115,8 @@ def main():
     ap.add_argument("--passes-per-step", type=int, default=16)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--accel", type=int, default=0)
+    ap.add_argument("--pipeline", type=int, default=0)
+    ap.add_argument("--passes-in-flight", type=int, default=0)
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -133,10 +149,12 @@ def main():
 
     work = None
     if rank == 0:
-        work = measure_work(scene, params, device, 4, args.seed, args.accel)
+        work = measure_work(scene, params, device, 4, args.seed, args.accel, args.pipeline)
 
     opt = capi.Options()
     opt.accel = args.accel
+    opt.pipeline = args.pipeline
+    opt.passes_in_flight = args.passes_in_flight
     ctx = capi.Context(scene, params, opt, device)
     sum_dev = torch.zeros((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
 
@@ -177,9 +195,11 @@ def main():
         value = pixel_samples / elapsed / 1e6
         st = ctx.stats()
         kernels = {k["name"]: k for k in st["kernels"]}
-        dom = max(kernels.values(), key=lambda k: k["ms"])
+        dom = max((k for k in kernels.values() if work["bytes_per_pixel_sample"].get(k["name"])), key=lambda k: k["ms"])
         dom_ms = dom["ms"] / max(1, dom["launches"])
-        dom_bytes = work["bytes_per_pixel_sample"].get(dom["name"], 0.0) * (dom["units"] / max(1, dom["launches"]))
+        # bytes of one launch = bytes per pixel-sample x pixel-samples of one batch / launches per batch
+        n_batches = max(1, min(k["launches"] for k in kernels.values()))
+        dom_bytes = work["bytes_per_pixel_sample"].get(dom["name"], 0.0) * (pixel_samples / ngpu) / max(1, dom["launches"])
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -195,7 +215,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: Cornell box, dielectric + perfect-mirror spheres, {W}x{H}",
                        "passes_per_step": pps, "spp_total": total_passes, "passes_per_gpu": args.steps * pps,
-                       "accel": "lbvh" if args.accel == 0 else "linear", "partition": f"passes round-robin over {ngpu} GPU(s)"},
+                       "accel": "lbvh" if args.accel == 0 else "linear", "pipeline": args.pipeline,
+                       "passes_in_flight": args.passes_in_flight or "auto", "partition": f"passes round-robin over {ngpu} GPU(s)"},
             "mrays_per_s": value * work["rays_per_pixel_sample"],
             "rays_per_pixel_sample": work["rays_per_pixel_sample"],
             "mean_radiance": [float(x) for x in (img.reshape(-1, 3).mean(0) / total_passes)],

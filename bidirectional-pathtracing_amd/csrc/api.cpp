@@ -63,10 +63,11 @@ m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
     return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
 }
 
-enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_PAIR_PROCESS, K_INTERSECT, K_VISIBILITY, K_NUM };
-const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_pair_process",
-                                   "k_intersect_batch", "k_visibility_batch"};
-constexpr int kLastRenderKernel = K_PAIR_PROCESS;
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_PAIR_PROCESS, K_WF_GEN, K_WF_BOUNCE, K_WF_TAIL,
+                K_INTERSECT, K_VISIBILITY, K_NUM };
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_pair_process", "k_wf_gen",
+                                   "k_wf_bounce", "k_wf_tail", "k_intersect_batch", "k_visibility_batch"};
+constexpr int kLastRenderKernel = K_WF_TAIL;
 
 struct TimedLaunch {
     hipEvent_t start, stop;
@@ -116,6 +117,9 @@ struct ubdpt_context {
     uint64_t* d_pairs = nullptr;
     unsigned long long pair_capacity = 0;
     unsigned long long* d_pair_count = nullptr;
+    double* d_carry = nullptr;
+    uint32_t* d_wf_trace_q = nullptr;
+    uint32_t* d_wf_count = nullptr;
 
     std::atomic<bool> stop{false};
     std::mutex mu;
@@ -159,6 +163,7 @@ struct ubdpt_context {
         hipFree(E.v); hipFree(E.object); hipFree(E.flags); hipFree(E.count);
         hipFree(L.v); hipFree(L.object); hipFree(L.flags); hipFree(L.count);
         hipFree(d_ovf); hipFree(d_counters); hipFree(d_pairs); hipFree(d_pair_count);
+        hipFree(d_carry); hipFree(d_wf_trace_q); hipFree(d_wf_count);
         if (stream) hipStreamDestroy(stream);
     }
 };
@@ -428,6 +433,12 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         c->pair_capacity = c->cap_paths * 24;
         ck(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * c->pair_capacity));
         ck(hipMalloc((void**)&c->d_pair_count, sizeof(unsigned long long)));
+        {
+            uint64_t n2 = 2 * c->cap_paths;
+            ck(hipMalloc((void**)&c->d_carry, sizeof(double) * 7 * n2));
+            ck(hipMalloc((void**)&c->d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
+            ck(hipMalloc((void**)&c->d_wf_count, sizeof(uint32_t) * 16 * (kWfDepth + 2)));
+        }
         ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
@@ -477,22 +488,42 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.ovf = c->d_ovf; A.ovf_stride = A.E.n;
         A.counters = c->d_counters;
         A.pairs = c->d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = c->d_pair_count;
+        A.carry = c->d_carry; A.wf_trace_q = c->d_wf_trace_q; A.wf_count = c->d_wf_count;
         double units = (double)A.E.n;
-        A.counters = c->d_counters + K_EYE * kNumCounters;
-        c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
-        A.counters = c->d_counters + K_LIGHT * kNumCounters;
-        c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
+        // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
+        unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
+        uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
+        if (c->opt.pipeline == 0) {
+            // wavefront subpath generation: gen, kWfDepth x (trace, shade), tail
+            HIPCK(c, hipMemsetAsync(c->d_wf_count, 0, sizeof(uint32_t) * 16 * (kWfDepth + 2), c->stream));
+            A.ovf_stride = pstride;
+            A.counters = c->d_counters + K_WF_GEN * kNumCounters;
+            c->beginTimed(K_WF_GEN, 2 * units); launchWfGen(A, stats, c->stream); c->endTimed();
+            A.counters = c->d_counters + K_WF_BOUNCE * kNumCounters;
+            for (uint32_t d = 0; d < kWfDepth; d++) {
+                c->beginTimed(K_WF_BOUNCE, d == 0 ? units : 0); launchWfBounce(A, d, pblocks, stats, c->stream); c->endTimed();
+            }
+            A.counters = c->d_counters + K_WF_TAIL * kNumCounters;
+            c->beginTimed(K_WF_TAIL, units); launchWfTail(A, kWfDepth, pblocks, stats, c->stream); c->endTimed();
+        } else {
+            A.ovf_stride = A.E.n;
+            A.counters = c->d_counters + K_EYE * kNumCounters;
+            c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
+            A.counters = c->d_counters + K_LIGHT * kNumCounters;
+            c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
+        }
         if (c->opt.pipeline == 1) {
+            A.ovf_stride = A.E.n;
             A.counters = c->d_counters + K_CONNECT * kNumCounters;
             c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
         } else {
             HIPCK(c, hipMemsetAsync(c->d_pair_count, 0, sizeof(unsigned long long), c->stream));
+            A.ovf_stride = A.E.n;
             A.counters = c->d_counters + K_PAIR_ENUM * kNumCounters;
             c->beginTimed(K_PAIR_ENUM, units); launchPairEnum(A, stats, c->stream); c->endTimed();
             A.counters = c->d_counters + K_PAIR_PROCESS * kNumCounters;
-            unsigned blocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
-            A.ovf_stride = (uint64_t)blocks * 256 > A.E.n ? (uint64_t)blocks * 256 : A.E.n;
-            c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, blocks, stats, c->stream); c->endTimed();
+            A.ovf_stride = pstride;
+            c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, pblocks, stats, c->stream); c->endTimed();
         }
         HIPCK(c, hipGetLastError());
         done += nb;

@@ -19,7 +19,16 @@ struct RenderArgs {
     uint64_t* pairs;                  // connection queue: (path << 16) | (s << 8) | t
     unsigned long long pair_capacity;
     unsigned long long* pair_count;   // device counter, zeroed before every batch
+    // wavefront subpath generation (wavefront.h); subpath id in [0, 2n)
+    double* carry;           // [7][2n]: ray direction, BSDF value, pdf of the last scattering
+    uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
+    uint32_t* wf_count;      // [depth][16] queue lengths ([d][0] is used), zeroed before every batch
 };
+
+constexpr uint32_t kWfDepth = 6;  // bounces run as wavefront launches before the tail loop takes over
+void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
+void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
+void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 
 constexpr int kNumCounters = 16;
 

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
     }
     E.count[gid] = n;
     if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
-    if (STATS) flushTally(ty, A.counters, n, 0);
+    if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
@@ -359,12 +359,16 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
         }
     }
     L.count[gid] = n;
-    if (STATS) flushTally(ty, A.counters, 0, n);
+    if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
+}  // namespace ub
+#include "wavefront.h"
+namespace ub {
+
 // ---------------------------------------------------------------------------------------------------
-// connections: the (s,t) loop of renderPixel (ubdptrenderer.cpp:103-149)
+// connections: the (s,t) loop of renderPixel (ubdptrenderer.cpp:103-149), one pixel-sample per lane
 // ---------------------------------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
     Tally ty;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
     uint32_t nE = E.count[gid], nL = L.count[gid];
+    if (STATS) { Tally t0; flushTally(t0, A.counters, nE, nL); }
     d3 I = mk3(0, 0, 0);
     d3 lens_pos = E.ld3(F_POS, 0, gid);
     d3 lens_a = E.ld3(F_A, 0, gid);
@@ -485,6 +490,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
         for (uint32_t s = 0; s < nL; s++) cL += L.specular(s, gid) ? 0u : 1u;
     }
     uint32_t cnt = cE * cL;
+    if (STATS && active) { Tally t0; flushTally(t0, A.counters, nE, nL); }
     uint32_t incl = waveInclusiveScan(cnt);
     uint32_t total = __shfl(incl, 63, 64);
     unsigned long long base = 0;
@@ -650,6 +656,19 @@ void launchLight(const RenderArgs& A, bool stats, hipStream_t s) {
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_connect<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_connect<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+}
+void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s) {
+    unsigned g = gridFor(2 * A.E.n);
+    if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(g), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_wf_gen<false>, dim3(g), dim3(kBlock), 0, s, A);
+}
+void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_wf_bounce<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    else hipLaunchKernelGGL(k_wf_bounce<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+}
+void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_wf_tail<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    else hipLaunchKernelGGL(k_wf_tail<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
 }
 void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);

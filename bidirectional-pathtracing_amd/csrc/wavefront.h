@@ -1,0 +1,388 @@
+// wavefront.h — eye and light subpath generation as a wavefront pipeline (included by render.hip).
+//
+// computeEyeSubpath / computeLightSubpath (uengine/ubdptrenderer.cpp:224-594) are loops of
+// "intersect, decide, scatter, push". Run one loop per lane and a wave idles until its longest path
+// ends. Here every bounce is one launch over the compacted queue of live subpaths:
+//
+//   k_wf_gen     primary rays (camera, :231-257) and emission rays (:413-454) for the whole batch
+//   k_wf_bounce  per workgroup chunk of 256 live subpaths:
+//                (1) closest hit through the LBVH and lobe choice (uapp/material.h);
+//                (2) counting sort of the chunk by (eye|light, lobe) in LDS: the lobe queues live
+//                    in LDS, and after the sort a wave shades one BSDF;
+//                (3) Russian roulette and pdf bookkeeping for the hit, s=0 emission sample, BSDF
+//                    sampling, vertex push, next ray;
+//                (4) survivors are appended to the next queue: ballot per wave, ONE global atomic
+//                    per chunk.
+//   k_wf_tail    after kWfDepth bounces the few survivors (long specular chains) finish in a per-lane loop
+//
+// Subpath id: [0, N) are the eye subpaths, [N, 2N) the light subpaths of the batch's N pixel-samples.
+#pragma once
+
+namespace ub {
+
+struct Carry {  // what a subpath keeps between two bounces besides its stored vertices
+    d3 dir;     // direction of the ray leaving the last vertex
+    d3 fs;      // BSDF value and pdf of the scattering at the last vertex
+    double p_psa;  // (light subpath before its first hit: dirT.y of the emission sample)
+};
+
+DEV void loadCarry(const RenderArgs& A, uint64_t id, Carry& c) {
+    uint64_t n2 = 2 * A.E.n;
+    c.dir = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
+    c.fs = mk3(A.carry[3 * n2 + id], A.carry[4 * n2 + id], A.carry[5 * n2 + id]);
+    c.p_psa = A.carry[6 * n2 + id];
+}
+DEV void storeCarry(const RenderArgs& A, uint64_t id, const Carry& c) {
+    uint64_t n2 = 2 * A.E.n;
+    A.carry[id] = c.dir.x; A.carry[n2 + id] = c.dir.y; A.carry[2 * n2 + id] = c.dir.z;
+    A.carry[3 * n2 + id] = c.fs.x; A.carry[4 * n2 + id] = c.fs.y; A.carry[5 * n2 + id] = c.fs.z;
+    A.carry[6 * n2 + id] = c.p_psa;
+}
+
+// Appends the lanes with pred == true to a queue: one ballot, one atomic per wave.
+DEV uint32_t waveReserve(bool pred, uint32_t* counter) {
+    unsigned long long m = __ballot(pred);
+    if (m == 0) return 0;
+    int lane = threadIdx.x & 63;
+    int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+}
+
+constexpr int kWfRegions = 8;   // (light ? 4 : 0) + lobe + 1
+constexpr int kWfQStride = 16;  // counters per depth: [0] trace queue length, [1..8] lobe queue lengths
+
+DEV Rng pathRng(const RenderArgs& A, uint64_t i, bool light, uint64_t& pixel) {
+    uint64_t pass;
+    uint32_t px, py;
+    decodePath(A, i, pass, pixel, px, py);
+    Rng r;
+    r.key = pathKey(A.seed, pass, pixel);
+    r.stream = light ? STREAM_LIGHT : STREAM_EYE;
+    return r;
+}
+
+// One bounce of one subpath after its ray found `hit` with the lobe `lobe` already chosen:
+// the second half of one loop iteration of computeEyeSubpath / computeLightSubpath followed by the
+// first half of the next. Returns true when a vertex was pushed; `ray` and `cy` then describe the
+// next ray. n = subpath.size() on entry, updated on push.
+template <bool STATS, bool LIGHT>
+DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& rng, uint32_t& n, Ray& ray,
+                   const Closest& hit, int lobe, Carry& cy, Tally& ty) {
+    const DScene& S = A.S;
+    const PathStore& P = LIGHT ? A.L : A.E;
+    uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+    Vertex nv;
+    surfacePoint(S, ray, hit, nv.sp);
+    nv.sp.lobe = lobe;
+    nv.p_light_A = 0; nv.p_eye_A = 0; nv.specular = false;
+    Tail cur;
+    cur.pos = P.ld3(F_POS, n - 1, i);
+    cur.Ns = P.ld3(F_NS, n - 1, i);
+    cur.p_eye_A = P.ld(F_PE, n - 1, i);
+    cur.specular = P.specular(n - 1, i);
+    d3 cur_a = P.ld3(F_A, n - 1, i);
+    bool prev_specular = false;
+    if (n == 1) {
+        nv.a = cur_a;
+        if (!LIGHT) nv.p_eye_A = 1.0 / S.image_plane_area;  // :265-267
+        else {                                              // :463-472, hit still in object-local space
+            double G = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
+            nv.p_light_A = (1 / (2.0 * kPi * cy.p_psa)) * G;
+        }
+    } else {
+        d3 prev_pos = P.ld3(F_POS, n - 2, i), prev_Ns = P.ld3(F_NS, n - 2, i);
+        prev_specular = P.specular(n - 2, i);
+        double fs_sum = cy.fs.x + cy.fs.y + cy.fs.z;
+        if (!(cy.p_psa > 0) || !(fs_sum > 0)) return false;  // :346 / :537
+        double q;
+        if (n < S.min_depth) q = 1.0;
+        else {
+            q = fmin(1.0, (fs_sum / 3.0) / cy.p_psa);
+            if (rng(hitDim(n - 1, DIM_ROULETTE)) > q) return false;
+        }
+        if (cur.specular) {
+            nv.a = cur_a * cy.fs;
+            if (!LIGHT) { nv.p_eye_A = q * cy.p_psa; P.st(F_PL, n - 2, i, q * cy.p_psa); }
+            else        { nv.p_light_A = q * 1.0;    P.st(F_PE, n - 2, i, q * 1.0); }
+        } else {
+            d3 a = cy.fs / cy.p_psa;
+            // G_next uses the new hit's OBJECT-LOCAL position and normal, as the reference does (:389-393, :578-582)
+            double G_next = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
+            nv.a = cur_a * a;
+            if (!LIGHT) {
+                double G_prev = geomAbs(cur.pos, cur.Ns, prev_pos, prev_Ns);
+                nv.p_eye_A = q * cy.p_psa * G_next;
+                P.st(F_PL, n - 2, i, q * cy.p_psa * G_prev);
+            } else {
+                double G_prev = geomAbs(prev_pos, prev_Ns, cur.pos, cur.Ns);
+                nv.p_light_A = q * cy.p_psa * G_next;
+                P.st(F_PE, n - 2, i, q * cy.p_psa * G_prev);
+            }
+        }
+    }
+    const DObject& obj = S.objects[nv.sp.object];
+    if (lobe == LOBE_NONE) {
+        if (!LIGHT) {  // :273-283
+            nv.sp.pos = transformPoint(obj.W, nv.sp.pos);
+            nv.sp.Ns = transformVectorT(obj.invW, nv.sp.Ns);
+            d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
+            if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+        }
+        return false;
+    }
+    if (n >= S.max_path_vertices) { if (STATS) ty.capped++; return false; }
+    d3 lTs = nv.sp.Ts, lNs = nv.sp.Ns, lBs = nv.sp.Bs;
+    Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
+    d3 w = transformVector(obj.invW, -ray.d);
+    d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+    double p_psa;
+    d3 fs, dirT;
+    if (!bsdfScatter(lobe, obj.mat_a, tex, fr, w, rng(hitDim(n, DIM_SCATTER_1)), rng(hitDim(n, DIM_SCATTER_2)), dirT,
+                     p_psa, fs, nv.specular))
+        return false;
+    finishVertex(obj, nv, dirT);
+    if (!LIGHT) {
+        d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
+        if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+    }
+    storeVertex(P, n, i, nv);
+    n++;
+    P.count[i] = n;
+    ray.o = nv.sp.pos;
+    ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
+    cy.dir = ray.d; cy.fs = fs; cy.p_psa = p_psa;
+    return true;
+}
+
+// ---- generation ---------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
+    uint64_t id = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const DScene& S = A.S;
+    uint64_t N = A.E.n;
+    bool live = false;
+    if (id < 2 * N) {
+        bool light = id >= N;
+        uint64_t i = light ? id - N : id;
+        uint64_t pass, pixel;
+        uint32_t px, py;
+        decodePath(A, i, pass, pixel, px, py);
+        Rng rng{pathKey(A.seed, pass, pixel), light ? (uint32_t)STREAM_LIGHT : (uint32_t)STREAM_EYE};
+        Carry cy;
+        cy.fs = mk3(0, 0, 0); cy.p_psa = 0; cy.dir = mk3(0, 0, 0);
+        if (!light) {
+            uint32_t pixel_sample = (uint32_t)(pass % S.num_pixel_strata);
+            uint32_t lens_sample = (uint32_t)(pass % S.num_lens_strata);
+            d2 disk = sampleUnitDiskStratified(S.num_lens_strata, lens_sample, rng(DIM_LENS_X), rng(DIM_LENS_Y));
+            d3 lens_pointV = mk3(S.lens_radius * disk.x, S.lens_radius * disk.y, 0);
+            Vertex lens;
+            lens.a = mk3(1.0, 1.0, 1.0);
+            lens.sp.pos = mul_xyz(S.invV, lens_pointV, 1.0);
+            lens.sp.Ns = lens.sp.Ng = transformVector(S.invV, mk3(0, 0, 1));
+            lens.sp.Ts = transformVector(S.invV, mk3(1, 0, 0));
+            lens.sp.Bs = transformVector(S.invV, mk3(0, 1, 0));
+            lens.sp.tex_u = 0; lens.sp.tex_v = 0; lens.sp.object = -1; lens.sp.lobe = LOBE_NONE; lens.sp.face = 0;
+            lens.p_eye_A = 1.0 / S.lens_area;  // lens_area is 0 in the reference -> +inf
+            lens.p_light_A = 0;
+            lens.specular = false;
+            storeVertex(A.E, 0, i, lens);
+            A.E.count[i] = 1;
+            d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
+            d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
+                                  1.0 - ((double)py + pp.y) * S.pixel_height, S.image_plane_distance);
+            image_pointV = normalize(image_pointV);
+            d3 focus_plane_pointV = image_pointV * (S.focus_plane_distance / image_pointV.z);
+            cy.dir = transformVector(S.invV, focus_plane_pointV - lens_pointV);
+            live = true;
+        } else if (S.num_emitters > 0) {
+            double p = rng(DIM_EMITTER);
+            int32_t ei = -1;
+            for (uint32_t k = 0; k < S.num_emitters; k++) {
+                int32_t e = S.emitters[k];
+                double pe = S.objects[e].prob;
+                if (p < pe) { ei = e; break; }
+                p -= pe;
+            }
+            if (ei < 0) ei = S.emitters[S.num_emitters - 1];
+            const DObject& em = S.objects[ei];
+            Vertex ev;
+            emitterRandomPoint(S, em, rng, ev.sp.pos, ev.sp.Ng, ev.sp.Ns, ev.sp.Ts, ev.sp.Bs);
+            ev.sp.tex_u = 0; ev.sp.tex_v = 0; ev.sp.object = ei; ev.sp.lobe = LOBE_NONE; ev.sp.face = 0;
+            ev.a = em.power;
+            ev.p_light_A = em.prob * (1.0 / em.area);
+            ev.p_eye_A = 0;
+            ev.specular = false;
+            storeVertex(A.L, 0, i, ev);
+            A.L.count[i] = 1;
+            d3 dirT = samplePosHemUniform(rng(DIM_EMIT_ANGLE), rng(DIM_EMIT_V));
+            cy.dir = float_tnb_mul(ev.sp.Ts, ev.sp.Ns, ev.sp.Bs, dirT);
+            cy.p_psa = dirT.y;
+            live = true;
+        } else {
+            A.L.count[i] = 0;
+        }
+        if (live) storeCarry(A, id, cy);
+    }
+}
+
+// ---- one bounce of every live subpath -------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t depth) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ uint32_t s_id[kBlock];
+    __shared__ int32_t s_obj[kBlock];
+    __shared__ uint32_t s_face[kBlock];
+    __shared__ double s_d[kBlock], s_u[kBlock], s_v[kBlock];
+    __shared__ uint32_t s_cnt[kWfRegions + 1];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const DScene& S = A.S;
+    const uint64_t N = A.E.n;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    // depth 0 walks all 2N subpaths in id order, later depths the queue the previous bounce wrote
+    const uint64_t total = depth == 0 ? 2 * N : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * 2 * N;
+    uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
+    uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * 2 * N;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
+        if (tid <= kWfRegions) s_cnt[tid] = 0;
+        __syncthreads();
+        // (1) trace + lobe choice
+        uint64_t j = base + tid;
+        int region = kWfRegions;  // dead
+        uint32_t id = 0;
+        Closest hit;
+        hit.object = -1; hit.face = 0; hit.d = 0; hit.u = 0; hit.v = 0;
+        if (j < total) {
+            id = depth == 0 ? (uint32_t)j : q[j];
+            bool light = id >= N;
+            uint64_t i = light ? id - N : id;
+            const PathStore& P = light ? A.L : A.E;
+            uint32_t n = P.count[i];
+            if (n > 0) {
+                Ray ray;
+                ray.o = P.ld3(F_POS, n - 1, i);
+                uint64_t n2 = 2 * N;
+                ray.d = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
+                hit = closestHit<STATS>(S, ray, st, ty);
+                if (hit.object >= 0) {
+                    uint64_t pixel;
+                    Rng rng = pathRng(A, i, light, pixel);
+                    int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
+                    // a light subpath ends at an absorbing hit (:460, :527)
+                    if (!(light && lobe == LOBE_NONE)) region = (light ? 4 : 0) + lobe + 1;
+                }
+            }
+        }
+        // (2) counting sort of the chunk by region, in LDS
+        uint32_t rank = 0;
+        if (region < kWfRegions) rank = atomicAdd(&s_cnt[region], 1u);
+        __syncthreads();
+        uint32_t start[kWfRegions + 1];
+        start[0] = 0;
+#pragma unroll
+        for (int r = 0; r < kWfRegions; r++) start[r + 1] = start[r] + s_cnt[r];
+        const uint32_t live = start[kWfRegions];
+        if (region < kWfRegions) {
+            uint32_t slot = rank;
+#pragma unroll
+            for (int r = 0; r < kWfRegions; r++) slot += (r < region) ? s_cnt[r] : 0u;
+            s_id[slot] = id; s_obj[slot] = hit.object; s_face[slot] = hit.face;
+            s_d[slot] = hit.d; s_u[slot] = hit.u; s_v[slot] = hit.v;
+        }
+        __syncthreads();
+        // (3) shade the sorted chunk: lanes [start[r], start[r+1]) run lobe queue r
+        bool cont = false;
+        uint32_t sid = 0;
+        if (tid < live) {
+            int r = 0;
+#pragma unroll
+            for (int k = 1; k < kWfRegions; k++) r += (tid >= start[k]) ? 1 : 0;
+            sid = s_id[tid];
+            Closest h2;
+            h2.object = s_obj[tid]; h2.face = s_face[tid]; h2.d = s_d[tid]; h2.u = s_u[tid]; h2.v = s_v[tid];
+            bool light = r >= 4;
+            int lobe = (r & 3) - 1;
+            uint64_t i = light ? sid - N : sid;
+            const PathStore& P = light ? A.L : A.E;
+            uint32_t n = P.count[i];
+            uint64_t pixel;
+            Rng rng = pathRng(A, i, light, pixel);
+            Carry cy;
+            loadCarry(A, sid, cy);
+            Ray ray;
+            ray.o = P.ld3(F_POS, n - 1, i);
+            ray.d = cy.dir;
+            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, h2, lobe, cy, ty)
+                         : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, h2, lobe, cy, ty);
+            if (cont) storeCarry(A, sid, cy);
+        }
+        // (4) survivors -> next queue, one global atomic per chunk
+        unsigned long long m = __ballot(cont);
+        if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) tot += s_wave[w];
+            s_base = tot ? atomicAdd(&next_cnt[0], tot) : 0u;
+        }
+        __syncthreads();
+        if (cont) {
+            uint32_t pos = s_base + (uint32_t)__popcll(m & ((1ULL << (tid & 63)) - 1ULL));
+            for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
+            next_q[pos] = sid;
+        }
+        __syncthreads();
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---- tail: survivors of the last wavefront bounce finish in a per-lane loop ---------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A, uint32_t depth) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const DScene& S = A.S;
+    uint64_t N = A.E.n;
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    uint32_t total = A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * 2 * N;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    for (uint64_t j = gid; j < total; j += nthreads) {
+        uint32_t id = q[j];
+        bool light = id >= N;
+        uint64_t i = light ? id - N : id;
+        const PathStore& P = light ? A.L : A.E;
+        uint32_t n = P.count[i];
+        uint64_t pixel;
+        Rng rng = pathRng(A, i, light, pixel);
+        Carry cy;
+        loadCarry(A, id, cy);
+        Ray ray;
+        ray.o = P.ld3(F_POS, n - 1, i);
+        ray.d = cy.dir;
+        for (;;) {
+            Closest hit = closestHit<STATS>(S, ray, st, ty);
+            if (hit.object < 0) break;
+            int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
+            if (light && lobe == LOBE_NONE) break;
+            bool cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty)
+                              : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty);
+            if (!cont) break;
+        }
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+}  // namespace ub
