@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libubdpt.so")
+# UBDPT_LIB selects another build of the same library (e.g. an experimental kernel variant)
+LIB_PATH = os.environ.get("UBDPT_LIB") or os.path.join(HERE, "lib", "libubdpt.so")
 
 # status codes (include/ubdpt.h)
 SUCCESS, UNINITIALIZED, INVALID_SCENE, INVALID_FORMAT, STOPPED, NO_DATA, ERROR, INVALID_ARG, NO_DEVICE, HIP_ERROR = range(10)

@@ -157,7 +157,89 @@ DEV bool t1Pixel(const DScene& S, d3 light_pos, d3 lens_pos, uint32_t& px, uint3
     return true;
 }
 
-// connectionFactor after the specular and visibility tests (ubdptrenderer.cpp:612-690).
+// The two same-side tests of UBsdfLambertian::samplePSA / pPSA (ubsdflambertian.cpp:17-23, 35-41) for
+// the world-space directions a and b leaving vertex v. The reference normalises the tangent-space
+// and the re-expanded vectors first; normalising scales by a positive number, so the signs tested
+// here are the same.
+DEV bool lambertSameSide(const ConnVertex& v, d3 a, d3 b) {
+    m3 TNB = mk_m3(v.Ts, v.Ns, v.Bs);
+    d3 aT = rowmul(a, TNB), bT = rowmul(b, TNB);
+    if (aT.y * bT.y <= 0) return false;
+    d3 aL = mul(TNB, aT), bL = mul(TNB, bT);
+    return !(dot(v.Ng, aL) * dot(v.Ng, bL) <= 0);
+}
+
+// Lambertian-only form of connectionFactorTail + misWeight below: a connected vertex is never
+// specular (ubdptrenderer.cpp:604), and every non-specular surface vertex carries the Lambertian
+// lobe, whose value (tex/pi) and pdf (1/pi) are constants once the same-side tests pass.
+// Returns false when the connection contributes nothing; otherwise c (connection factor) and w (MIS weight).
+DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+                        const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, d3& c, double& w) {
+    d3 ce = vl.pos - ve.pos;
+    double ce_length2 = dot(ce, ce);
+    ce = ce / sqrt(ce_length2);
+    double d1 = dot(ce, ve.Ng);
+    double d2 = dot(-ce, vl.Ng);
+    if ((d1 <= 0) || (d2 <= 0)) return false;
+    d1 = dot(ce, ve.Ns);
+    d2 = dot(-ce, vl.Ns);
+    double G = (d1 * d2) / ce_length2;
+    d3 fs1, fs2;
+    if (s == 1)
+        fs1 = mk3(1, 1, 1) * (1.0 / (2.0 * kPi * d2));
+    else {
+        if (!lambertSameSide(vl, lprev - vl.pos, ve.pos - vl.pos)) return false;
+        fs1 = (1.0 / kPi) * textureSample(S, S.objects[vl.object].texture, vl.tex_u, vl.tex_v);
+        if (fs1.x + fs1.y + fs1.z <= 0) return false;
+    }
+    if (t == 1) {
+        d3 edgeV = mul_xyz(S.V, ce, 0.0);
+        double d = S.image_plane_distance / edgeV.z;
+        double d2_image_plane = dot(-edgeV, mk3(0, 0, -1));
+        double G_image_plane = fabs(d1 * d2_image_plane) / (d * d);
+        fs2 = mk3(1, 1, 1) * ((1.0 / (S.image_plane_area)) / G_image_plane);
+    } else {
+        if (!lambertSameSide(ve, vl.pos - ve.pos, eprev - ve.pos)) return false;
+        fs2 = (1.0 / kPi) * textureSample(S, S.objects[ve.object].texture, ve.tex_u, ve.tex_v);
+        if (fs2.x + fs2.y + fs2.z <= 0) return false;
+    }
+    c = fs1 * fs2 * G;
+    // weight (ubdptrenderer.cpp:779-844); the pdfs of p_sp1 / p_sm1 are 1/pi because the same-side
+    // tests above are exactly the tests of pPSA for the same pair of directions
+    w = 1.0;
+    double ratio = 1.0;
+    if (t > 1) {
+        ratio = (s == 1) ? (1.0 / (2.0 * kPi * d2)) : (1.0 / kPi);
+        ratio *= G;
+        ratio = ratio / ve.p_eye_A;
+        if (!E.specular(t - 2, i)) w += ratio * ratio;
+    }
+    if (t > 2)
+        for (int v = (int)t - 2; v > 0; v--) {
+            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
+            if (E.specular(v, i)) continue;
+            if (E.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    double p_eye_A = (t == 1) ? (1.0 / S.image_plane_area) : ((1.0 / kPi) * G);
+    ratio = (p_eye_A / vl.p_light_A);
+    if (s > 1) {
+        if (!L.specular(s - 2, i)) w += ratio * ratio;
+    } else
+        w += ratio * ratio;
+    if (s > 1)
+        for (int v = (int)s - 2; v >= 0; v--) {
+            ratio *= L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
+            if (L.specular(v, i)) continue;
+            if (v > 0)
+                if (L.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    w = 1.0 / w;
+    return true;
+}
+
+// connectionFactor after the specular and visibility tests (ubdptrenderer.cpp:612-690), any lobe.
 // lprev = light_subpath[s-2].pos (s > 1), eprev = eye_subpath[t-2].pos (t > 1).
 DEV bool connectionFactorTail(const DScene& S, const ConnVertex& vl, const ConnVertex& ve, uint32_t s, uint32_t t,
                               d3 lprev, d3 eprev, d3& c) {

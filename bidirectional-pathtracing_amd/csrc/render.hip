@@ -466,8 +466,13 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
     d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
     d3 c;
-    if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return;
-    double w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
+    double w;
+    if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
+        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, c, w)) return;
+    } else {
+        if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return;
+        w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
+    }
     if (STATS) { ty.conn++; ty.fb++; }
     if (t == 1) {
         if (STATS) ty.splat++;

@@ -3,7 +3,8 @@
 // Replaces UScene::intersectionPoint and UScene::visibility (uengine/uscene.cpp:21-66), which scan
 // every object and every face. Here a ray walks a world-space LBVH (64-byte two-child nodes) with a
 // per-lane stack whose first kLdsStack entries live in LDS ([entry][lane], bank = lane, conflict
-// free) and whose rare overflow goes to a per-lane slice of HBM. Candidate primitives are tested
+// free) and whose rare overflow goes to a per-lane slice of HBM. Boxes are tested in fp32 with a
+// conservative slab test; candidate primitives are tested
 // exactly as the reference tests them: in object-local space, in fp64, in the reference's operation
 // order (URay::intersectTriangle / intersectUnitSphere, uengine/ugeometry.cpp:70-114), including
 // the per-mesh bounding-sphere gate (uapp/mesh.cpp:120,167). The reference's "first object, first
@@ -133,19 +134,40 @@ DEV bool testPrimBlocks(const DScene& S, const Ray& r, const Prim& pr, LocalCach
     return true;
 }
 
-// ---- slab test against a stored fp32 box, evaluated in fp64 -------------------------------------
-// Boxes are rounded outward and padded at build time (bvh.hip), so with fp64 slabs the test is
-// conservative for every ray parameter the fp64 primitive tests can accept.
-DEV bool slab(const float* lo, const float* hi, d3 o, d3 inv, double tmax, double& tnear) {
-    double t0 = ((double)lo[0] - o.x) * inv.x, t1 = ((double)hi[0] - o.x) * inv.x;
-    double tn = fmin(t0, t1), tf = fmax(t0, t1);
-    t0 = ((double)lo[1] - o.y) * inv.y; t1 = ((double)hi[1] - o.y) * inv.y;
-    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
-    t0 = ((double)lo[2] - o.z) * inv.z; t1 = ((double)hi[2] - o.z) * inv.z;
-    tn = fmax(tn, fmin(t0, t1)); tf = fmin(tf, fmax(t0, t1));
-    tnear = tn;
-    return tn <= tf && tf >= 0.0 && tn <= tmax;
+// ---- conservative fp32 slab test -----------------------------------------------------------------
+// The tree is walked in fp32 (half the VALU cost and registers of fp64); only the primitive tests
+// are fp64. The fp32 ray (origin and direction rounded to float) deviates from the fp64 ray by at
+// most 2^-24 (2|o| + M) inside a scene of magnitude M; boxes are padded by 2^-20 M at build time
+// (bvh.hip) and by `pad` = 2^-22 |o| per ray here, and the slab interval is widened by 2^-21
+// relative (more than the 2*gamma_3 bound of robust fp32 slab arithmetic), so a box is never
+// rejected for a ray parameter at which the fp64 primitive test can accept.
+struct RayF {
+    float ox, oy, oz;
+    float ix, iy, iz;  // 1 / direction
+    float pad;         // origin-magnitude dependent extra box padding
+};
+DEV RayF makeRayF(const Ray& r) {
+    RayF q;
+    q.ox = (float)r.o.x; q.oy = (float)r.o.y; q.oz = (float)r.o.z;
+    q.ix = 1.0f / (float)r.d.x; q.iy = 1.0f / (float)r.d.y; q.iz = 1.0f / (float)r.d.z;
+    q.pad = fmaxf(fabsf(q.ox), fmaxf(fabsf(q.oy), fabsf(q.oz))) * 2.384185791015625e-07f;  // 2^-22
+    return q;
 }
+DEV bool slabF(const float* lo, const float* hi, const RayF& q, float tmax, float& tnear) {
+    float t0 = ((lo[0] - q.pad) - q.ox) * q.ix, t1 = ((hi[0] + q.pad) - q.ox) * q.ix;
+    float tn = fminf(t0, t1), tf = fmaxf(t0, t1);
+    t0 = ((lo[1] - q.pad) - q.oy) * q.iy; t1 = ((hi[1] + q.pad) - q.oy) * q.iy;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    t0 = ((lo[2] - q.pad) - q.oz) * q.iz; t1 = ((hi[2] + q.pad) - q.oz) * q.iz;
+    tn = fmaxf(tn, fminf(t0, t1)); tf = fminf(tf, fmaxf(t0, t1));
+    const float k = 4.76837158203125e-07f;  // 2^-21
+    tn = tn - fabsf(tn) * k;
+    tf = tf + fabsf(tf) * k;
+    tnear = tn;
+    return tn <= tf && tf >= 0.0f && tn <= tmax;
+}
+// smallest float >= x (x > 0 or +inf)
+DEV float floatUp(double x) { return __double2float_ru(x); }
 
 // Per-lane traversal stack: LDS for the first kLdsStack entries, HBM beyond.
 struct Stack {
@@ -167,45 +189,48 @@ struct Stack {
     }
 };
 
-DEV d3 invDir(d3 d) { return mk3(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+constexpr int32_t kTraversalDone = kEmptyChild;
+
+// One traversal step from an internal node: tests both children, returns the next node to visit
+// (near child first, far child pushed) or pops / finishes when neither child is hit.
+DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool ordered,
+                    TraceCounters* tc) {
+    const BvhNode nd = S.nodes[node];
+    if (tc) tc->nodes++;
+    float tn0, tn1;
+    bool h0 = nd.child0 != kEmptyChild && slabF(nd.lo0, nd.hi0, q, tmax, tn0);
+    bool h1 = nd.child1 != kEmptyChild && slabF(nd.lo1, nd.hi1, q, tmax, tn1);
+    int32_t c0 = nd.child0, c1 = nd.child1;
+    if (h0 && h1) {
+        if (ordered && tn1 < tn0) { int32_t t = c0; c0 = c1; c1 = t; }
+        st.push(c1);
+        return c0;
+    }
+    if (h0) return c0;
+    if (h1) return c1;
+    return st.sp ? st.pop() : kTraversalDone;
+}
 
 // UScene::intersectionPoint through the LBVH. Returns the lexicographically smallest (d, object, face).
+// while-while form: every lane of the wave descends until it holds a leaf (or is done), then the
+// fp64 primitive tests of all lanes run together.
 DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack st, TraceCounters* tc) {
     Closest best;
     best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
     if (S.num_prims == 0) return best;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
-    d3 inv = invDir(r.d);
+    const RayF q = makeRayF(r);
+    float tmax = __builtin_inff();
     st.sp = 0;
     int32_t node = 0;
     for (;;) {
-        const BvhNode nd = S.nodes[node];
-        if (tc) tc->nodes++;
-        double tn0, tn1;
-        bool h0 = nd.child0 != kEmptyChild && slab(nd.lo0, nd.hi0, r.o, inv, best.d, tn0);
-        bool h1 = nd.child1 != kEmptyChild && slab(nd.lo1, nd.hi1, r.o, inv, best.d, tn1);
-        int32_t c0 = nd.child0, c1 = nd.child1;
-        if (h0 && c0 < 0) {
-            if (tc) tc->prims++;
-            testPrimClosest(S, r, S.prims[~c0], c, best);
-            h0 = false;
-        }
-        if (h1 && c1 < 0) {
-            if (tc) tc->prims++;
-            testPrimClosest(S, r, S.prims[~c1], c, best);
-            h1 = false;
-        }
-        if (h0 && h1) {
-            if (tn1 < tn0) { int32_t t = c0; c0 = c1; c1 = t; }
-            st.push(c1);
-            node = c0;
-        } else if (h0) node = c0;
-        else if (h1) node = c1;
-        else {
-            if (st.sp == 0) break;
-            node = st.pop();
-        }
+        while (node >= 0 && node != kTraversalDone) node = descend(S, node, q, tmax, st, true, tc);
+        if (node == kTraversalDone) break;
+        if (tc) tc->prims++;
+        testPrimClosest(S, r, S.prims[~node], c, best);
+        tmax = floatUp(best.d);
+        node = st.sp ? st.pop() : kTraversalDone;
     }
     return best;
 }
@@ -219,33 +244,16 @@ DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters* tc) 
     if (S.num_prims == 0) return true;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
-    d3 inv = invDir(r.d);
+    const RayF q = makeRayF(r);
+    const float tmax = floatUp(dist);
     st.sp = 0;
     int32_t node = 0;
     for (;;) {
-        const BvhNode nd = S.nodes[node];
-        if (tc) tc->nodes++;
-        double tn0, tn1;
-        bool h0 = nd.child0 != kEmptyChild && slab(nd.lo0, nd.hi0, r.o, inv, dist, tn0);
-        bool h1 = nd.child1 != kEmptyChild && slab(nd.lo1, nd.hi1, r.o, inv, dist, tn1);
-        int32_t c0 = nd.child0, c1 = nd.child1;
-        if (h0 && c0 < 0) {
-            if (tc) tc->prims++;
-            if (testPrimBlocks(S, r, S.prims[~c0], c, dist)) return false;
-            h0 = false;
-        }
-        if (h1 && c1 < 0) {
-            if (tc) tc->prims++;
-            if (testPrimBlocks(S, r, S.prims[~c1], c, dist)) return false;
-            h1 = false;
-        }
-        if (h0 && h1) { st.push(c1); node = c0; }
-        else if (h0) node = c0;
-        else if (h1) node = c1;
-        else {
-            if (st.sp == 0) break;
-            node = st.pop();
-        }
+        while (node >= 0 && node != kTraversalDone) node = descend(S, node, q, tmax, st, false, tc);
+        if (node == kTraversalDone) break;
+        if (tc) tc->prims++;
+        if (testPrimBlocks(S, r, S.prims[~node], c, dist)) return false;
+        node = st.sp ? st.pop() : kTraversalDone;
     }
     return true;
 }
