@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--accel", type=int, default=0)
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--passes-in-flight", type=int, default=0)
+    ap.add_argument("--dense-threshold", type=int, default=0,
+                    help="lanes of a wave that must own an (s,t) pair for it to be connected in place (0 = default)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -155,6 +157,7 @@ def main():
     opt.accel = args.accel
     opt.pipeline = args.pipeline
     opt.passes_in_flight = args.passes_in_flight
+    opt.reserved[0] = args.dense_threshold
     ctx = capi.Context(scene, params, opt, device)
     sum_dev = torch.zeros((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
 

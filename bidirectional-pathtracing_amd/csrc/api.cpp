@@ -63,10 +63,11 @@ m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
     return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
 }
 
-enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_PAIR_PROCESS, K_WF_GEN, K_WF_BOUNCE, K_WF_TAIL,
-                K_INTERSECT, K_VISIBILITY, K_NUM };
-const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_pair_process", "k_wf_gen",
-                                   "k_wf_bounce", "k_wf_tail", "k_intersect_batch", "k_visibility_batch"};
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_CONNECT_HYBRID, K_CONNECT_TILE, K_PAIR_PROCESS, K_PAIR_VISIBLE,
+                K_PAIR_EVAL, K_WF_GEN, K_WF_BOUNCE, K_WF_TRACE, K_WF_SHADE, K_WF_TAIL, K_INTERSECT, K_VISIBILITY, K_NUM };
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_connect_hybrid", "k_connect_tile",
+                                   "k_pair_process", "k_pair_visible", "k_pair_eval", "k_wf_gen", "k_wf_bounce", "k_wf_trace",
+                                   "k_wf_shade", "k_wf_tail", "k_intersect_batch", "k_visibility_batch"};
 constexpr int kLastRenderKernel = K_WF_TAIL;
 
 struct TimedLaunch {
@@ -113,11 +114,19 @@ struct ubdpt_context {
     PathStore E{}, L{};
     int32_t* d_ovf = nullptr;
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
+    int32_t* d_ovf_tile = nullptr;    // same, for the tiled connection kernel (8 lanes per pixel-sample)
+    uint64_t ovf_threads_tile = 0;
     unsigned long long* d_counters = nullptr;
     uint64_t* d_pairs = nullptr;
     unsigned long long pair_capacity = 0;
     unsigned long long* d_pair_count = nullptr;
     double* d_carry = nullptr;
+    int32_t* d_wf_hit_obj = nullptr;
+    uint32_t* d_wf_hit_face = nullptr;
+    double* d_wf_hit_duv = nullptr;
+    uint32_t* d_wf_hit_q = nullptr;
+    uint64_t* d_vis_pairs = nullptr;
+    uint32_t* d_vis_count = nullptr;
     uint32_t* d_wf_trace_q = nullptr;
     uint32_t* d_wf_count = nullptr;
 
@@ -162,8 +171,10 @@ struct ubdpt_context {
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         hipFree(E.v); hipFree(E.object); hipFree(E.flags); hipFree(E.count);
         hipFree(L.v); hipFree(L.object); hipFree(L.flags); hipFree(L.count);
-        hipFree(d_ovf); hipFree(d_counters); hipFree(d_pairs); hipFree(d_pair_count);
+        hipFree(d_ovf); hipFree(d_ovf_tile); hipFree(d_counters); hipFree(d_pairs); hipFree(d_pair_count);
         hipFree(d_carry); hipFree(d_wf_trace_q); hipFree(d_wf_count);
+        hipFree(d_wf_hit_obj); hipFree(d_wf_hit_face); hipFree(d_wf_hit_duv); hipFree(d_wf_hit_q); hipFree(d_vis_pairs);
+        hipFree(d_vis_count);
         if (stream) hipStreamDestroy(stream);
     }
 };
@@ -430,12 +441,21 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((st = allocStore(c, c->L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
         ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_threads));
+        c->ovf_threads_tile = ((c->cap_paths + 31) / 32) * 256;
+        ck(hipMalloc((void**)&c->d_ovf_tile, sizeof(int32_t) * kOverflowStack * c->ovf_threads_tile));
         c->pair_capacity = c->cap_paths * 24;
         ck(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * c->pair_capacity));
         ck(hipMalloc((void**)&c->d_pair_count, sizeof(unsigned long long)));
         {
             uint64_t n2 = 2 * c->cap_paths;
             ck(hipMalloc((void**)&c->d_carry, sizeof(double) * 7 * n2));
+            ck(hipMalloc((void**)&c->d_wf_hit_obj, sizeof(int32_t) * n2));
+            ck(hipMalloc((void**)&c->d_wf_hit_face, sizeof(uint32_t) * n2));
+            ck(hipMalloc((void**)&c->d_wf_hit_duv, sizeof(double) * 3 * n2));
+            // every 256-chunk is padded to whole waves: at most 63 extra entries per chunk
+            ck(hipMalloc((void**)&c->d_wf_hit_q, sizeof(uint32_t) * (n2 + 64 * (n2 / 256 + 2))));
+            ck(hipMalloc((void**)&c->d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
+            ck(hipMalloc((void**)&c->d_vis_count, sizeof(uint32_t)));
             ck(hipMalloc((void**)&c->d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
             ck(hipMalloc((void**)&c->d_wf_count, sizeof(uint32_t) * 16 * (kWfDepth + 2)));
         }
@@ -489,19 +509,33 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.counters = c->d_counters;
         A.pairs = c->d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = c->d_pair_count;
         A.carry = c->d_carry; A.wf_trace_q = c->d_wf_trace_q; A.wf_count = c->d_wf_count;
+        A.wf_hit_obj = c->d_wf_hit_obj; A.wf_hit_face = c->d_wf_hit_face; A.wf_hit_duv = c->d_wf_hit_duv;
+        A.wf_hit_q = c->d_wf_hit_q; A.vis_pairs = c->d_vis_pairs; A.vis_count = c->d_vis_count;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
         uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
-        if (c->opt.pipeline == 0) {
-            // wavefront subpath generation: gen, kWfDepth x (trace, shade), tail
+        // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, visible, eval (default)
+        //           1 = per-path subpath kernels + per-path connection loop
+        //           2 = per-path subpath kernels + global pair queue, one kernel per pair
+        //           3 = wavefront with fused trace+shade bounce kernel + in-place dense / queued sparse pairs
+        //           4 = wavefront small kernels + LDS-tiled connection kernel
+        const uint32_t pl = c->opt.pipeline;
+        if (pl == 0 || pl == 3 || pl == 4) {
             HIPCK(c, hipMemsetAsync(c->d_wf_count, 0, sizeof(uint32_t) * 16 * (kWfDepth + 2), c->stream));
             A.ovf_stride = pstride;
             A.counters = c->d_counters + K_WF_GEN * kNumCounters;
             c->beginTimed(K_WF_GEN, 2 * units); launchWfGen(A, stats, c->stream); c->endTimed();
-            A.counters = c->d_counters + K_WF_BOUNCE * kNumCounters;
             for (uint32_t d = 0; d < kWfDepth; d++) {
-                c->beginTimed(K_WF_BOUNCE, d == 0 ? units : 0); launchWfBounce(A, d, pblocks, stats, c->stream); c->endTimed();
+                if (pl == 3) {
+                    A.counters = c->d_counters + K_WF_BOUNCE * kNumCounters;
+                    c->beginTimed(K_WF_BOUNCE, d == 0 ? units : 0); launchWfBounce(A, d, pblocks, stats, c->stream); c->endTimed();
+                } else {
+                    A.counters = c->d_counters + K_WF_TRACE * kNumCounters;
+                    c->beginTimed(K_WF_TRACE, d == 0 ? units : 0); launchWfTrace(A, d, pblocks, stats, c->stream); c->endTimed();
+                    A.counters = c->d_counters + K_WF_SHADE * kNumCounters;
+                    c->beginTimed(K_WF_SHADE, d == 0 ? units : 0); launchWfShade(A, d, pblocks, stats, c->stream); c->endTimed();
+                }
             }
             A.counters = c->d_counters + K_WF_TAIL * kNumCounters;
             c->beginTimed(K_WF_TAIL, units); launchWfTail(A, kWfDepth, pblocks, stats, c->stream); c->endTimed();
@@ -512,18 +546,39 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.counters = c->d_counters + K_LIGHT * kNumCounters;
             c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
         }
-        if (c->opt.pipeline == 1) {
+        if (pl == 4) {
+            // one workgroup per 32 pixel-samples, 8 lanes per pixel-sample: lane ids stay below 8 * n
+            A.ovf_stride = c->ovf_threads_tile;
+            A.ovf = c->d_ovf_tile;
+            A.counters = c->d_counters + K_CONNECT_TILE * kNumCounters;
+            c->beginTimed(K_CONNECT_TILE, units); launchConnectTile(A, stats, c->stream); c->endTimed();
+            A.ovf = c->d_ovf;
+        } else if (pl == 1) {
             A.ovf_stride = A.E.n;
             A.counters = c->d_counters + K_CONNECT * kNumCounters;
             c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
         } else {
             HIPCK(c, hipMemsetAsync(c->d_pair_count, 0, sizeof(unsigned long long), c->stream));
             A.ovf_stride = A.E.n;
-            A.counters = c->d_counters + K_PAIR_ENUM * kNumCounters;
-            c->beginTimed(K_PAIR_ENUM, units); launchPairEnum(A, stats, c->stream); c->endTimed();
-            A.counters = c->d_counters + K_PAIR_PROCESS * kNumCounters;
+            if (pl == 3) {
+                uint32_t thr = c->opt.reserved[0] ? c->opt.reserved[0] : 40;
+                A.counters = c->d_counters + K_CONNECT_HYBRID * kNumCounters;
+                c->beginTimed(K_CONNECT_HYBRID, units); launchConnectHybrid(A, thr, stats, c->stream); c->endTimed();
+            } else {
+                A.counters = c->d_counters + K_PAIR_ENUM * kNumCounters;
+                c->beginTimed(K_PAIR_ENUM, units); launchPairEnum(A, stats, c->stream); c->endTimed();
+            }
             A.ovf_stride = pstride;
-            c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, pblocks, stats, c->stream); c->endTimed();
+            if (pl == 0) {
+                HIPCK(c, hipMemsetAsync(c->d_vis_count, 0, sizeof(uint32_t), c->stream));
+                A.counters = c->d_counters + K_PAIR_VISIBLE * kNumCounters;
+                c->beginTimed(K_PAIR_VISIBLE, units); launchPairVisible(A, pblocks, stats, c->stream); c->endTimed();
+                A.counters = c->d_counters + K_PAIR_EVAL * kNumCounters;
+                c->beginTimed(K_PAIR_EVAL, units); launchPairEval(A, pblocks, stats, c->stream); c->endTimed();
+            } else {
+                A.counters = c->d_counters + K_PAIR_PROCESS * kNumCounters;
+                c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, pblocks, stats, c->stream); c->endTimed();
+            }
         }
         HIPCK(c, hipGetLastError());
         done += nb;

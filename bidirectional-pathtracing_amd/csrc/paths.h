@@ -173,7 +173,9 @@ DEV bool lambertSameSide(const ConnVertex& v, d3 a, d3 b) {
 // specular (ubdptrenderer.cpp:604), and every non-specular surface vertex carries the Lambertian
 // lobe, whose value (tex/pi) and pdf (1/pi) are constants once the same-side tests pass.
 // Returns false when the connection contributes nothing; otherwise c (connection factor) and w (MIS weight).
-DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+// SL / SE: anything with ld(field, slot, i) and specular(slot, i) — the HBM PathStore or an LDS tile.
+template <class SL, class SE>
+DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, const ConnVertex& vl,
                         const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, d3& c, double& w) {
     d3 ce = vl.pos - ve.pos;
     double ce_length2 = dot(ce, ce);
@@ -278,7 +280,8 @@ DEV bool connectionFactorTail(const DScene& S, const ConnVertex& vl, const ConnV
 }
 
 // weight (ubdptrenderer.cpp:779-844) with p_sp1 (:693-735) and p_sm1 (:737-777) inlined.
-DEV double misWeight(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+template <class SL, class SE>
+DEV double misWeight(const DScene& S, const SL& L, const SE& E, uint64_t i, const ConnVertex& vl,
                      const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev) {
     double w = 1.0;
     double ratio = 1.0;

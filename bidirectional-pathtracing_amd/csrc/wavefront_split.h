@@ -1,0 +1,206 @@
+// wavefront_split.h — the wavefront stages as SMALL kernels (included by render.hip after wavefront.h).
+//
+// These kernels are bound by memory latency times occupancy: a bounce is a chain of ~25 dependent
+// memory phases, and a kernel that holds the traversal state AND the fp64 shading state needs
+// >200 VGPRs (2 waves per SIMD). Splitting at the natural seams keeps each kernel's live state small:
+//
+//   k_wf_trace     ray in, (object, face, d, u, v, lobe) out; the 256 subpaths of a chunk are ordered by
+//                  (eye|light, lobe) with a stable counting sort in LDS and appended to the hit
+//                  queue as one block: one global atomic per chunk, chunks padded to whole waves so
+//                  that a wave of the shade kernel sees one lobe (material-sorted queue)
+//   k_wf_shade     no traversal: pdf bookkeeping, s=0 sample, BSDF sampling, vertex push, next ray;
+//                  survivors -> next trace queue (one atomic per chunk)
+//   k_pair_visible the rejecting half of a connection, ending with the shadow ray; survivors -> queue
+//   k_pair_eval    connection factor, MIS weight, accumulation for the visible pairs only
+#pragma once
+
+namespace ub {
+
+constexpr uint32_t kQueueSentinel = 0xffffffffu;
+
+// Appends the lanes with pred to a queue with ONE global atomic per workgroup. Every lane of the
+// workgroup must call it. Returns the lane's slot (valid when pred).
+DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_t* s_base) {
+    const uint32_t tid = threadIdx.x;
+    unsigned long long m = __ballot(pred);
+    if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t tot = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) tot += s_wave[w];
+        *s_base = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = *s_base + (uint32_t)__popcll(m & ((1ULL << (tid & 63)) - 1ULL));
+    for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
+    __syncthreads();  // s_wave / s_base may be reused by the next call
+    return pos;
+}
+
+// ---- trace ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_wf_trace(RenderArgs A, uint32_t depth) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
+    __shared__ uint32_t s_base;
+    const DScene& S = A.S;
+    const uint64_t N = A.E.n;
+    const uint64_t n2 = 2 * N;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint64_t total = depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * n2;
+    uint32_t* hit_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 1;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
+        uint64_t j = base + tid;
+        int region = kWfRegions;  // dead
+        uint32_t id = 0;
+        if (j < total) {
+            id = depth == 0 ? (uint32_t)j : q[j];
+            bool light = id >= N;
+            uint64_t i = light ? id - N : id;
+            const PathStore& P = light ? A.L : A.E;
+            uint32_t n = P.count[i];
+            if (n > 0) {
+                Ray ray;
+                ray.o = P.ld3(F_POS, n - 1, i);
+                ray.d = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
+                Closest hit = closestHit<STATS>(S, ray, st, ty);
+                if (hit.object >= 0) {
+                    uint64_t pixel;
+                    Rng rng = pathRng(A, i, light, pixel);
+                    int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
+                    if (!(light && lobe == LOBE_NONE)) {  // a light subpath ends at an absorbing hit (:460, :527)
+                        region = (light ? 4 : 0) + lobe + 1;
+                        A.wf_hit_obj[id] = hit.object;
+                        A.wf_hit_face[id] = hit.face;
+                        A.wf_hit_duv[id] = hit.d; A.wf_hit_duv[n2 + id] = hit.u; A.wf_hit_duv[2 * n2 + id] = hit.v;
+                    }
+                }
+            }
+        }
+        // stable counting sort of the chunk by region: rank inside the wave by ballot, wave totals in LDS
+        uint32_t rank = 0;
+#pragma unroll
+        for (int r = 0; r < kWfRegions; r++) {
+            unsigned long long m = __ballot(region == r);
+            if (lane == 0) s_wcnt[r][wave] = (uint32_t)__popcll(m);
+            if (region == r) rank = (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
+        }
+        __syncthreads();
+        uint32_t slot = rank, live = 0;
+#pragma unroll
+        for (int r = 0; r < kWfRegions; r++)
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) {
+                uint32_t c = s_wcnt[r][w];
+                live += c;
+                if (r < region || (r == region && (uint32_t)w < wave)) slot += c;
+            }
+        const uint32_t padded = (live + 63u) & ~63u;  // whole waves: a shade wave never straddles two chunks
+        if (tid == 0) s_base = padded ? atomicAdd(hit_cnt, padded) : 0u;
+        __syncthreads();
+        if (region < kWfRegions) A.wf_hit_q[s_base + slot] = id | ((uint32_t)region << 29);
+        if (tid < padded - live) A.wf_hit_q[s_base + live + tid] = kQueueSentinel;
+        __syncthreads();
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---- shade ------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t depth) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint64_t N = A.E.n;
+    const uint64_t n2 = 2 * N;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint64_t total = (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride + 1];
+    uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
+    uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * n2;
+    Tally ty;
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
+        uint64_t j = base + tid;
+        bool cont = false;
+        uint32_t id = 0;
+        if (j < total) {
+            uint32_t e = A.wf_hit_q[j];
+            if (e != kQueueSentinel) {
+                id = e & 0x1fffffffu;
+                uint32_t r = e >> 29;
+                bool light = r >= 4;
+                int lobe = (int)(r & 3) - 1;
+                uint64_t i = light ? id - N : id;
+                const PathStore& P = light ? A.L : A.E;
+                uint32_t n = P.count[i];
+                uint64_t pixel;
+                Rng rng = pathRng(A, i, light, pixel);
+                Carry cy;
+                loadCarry(A, id, cy);
+                Ray ray;
+                ray.o = P.ld3(F_POS, n - 1, i);
+                ray.d = cy.dir;
+                Closest hit;
+                hit.object = A.wf_hit_obj[id]; hit.face = A.wf_hit_face[id];
+                hit.d = A.wf_hit_duv[id]; hit.u = A.wf_hit_duv[n2 + id]; hit.v = A.wf_hit_duv[2 * n2 + id];
+                cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty)
+                             : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty);
+                if (cont) storeCarry(A, id, cy);
+            }
+        }
+        uint32_t pos = blockAppend(cont, &next_cnt[0], s_wave, &s_base);
+        if (cont) next_q[pos] = id;
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+}
+
+// ---- connections: visibility, then evaluation -----------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_visible(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    unsigned long long total = *A.pair_count;
+    if (total > A.pair_capacity) total = A.pair_capacity;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Tally ty;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
+        unsigned long long j = base + tid;
+        bool vis = false;
+        uint64_t p = 0;
+        if (j < total) {
+            p = A.pairs[j];
+            uint32_t s = (uint32_t)((p >> 8) & 0xff), t = (uint32_t)(p & 0xff);
+            if (s != 0) vis = pairVisible<STATS>(A, p >> 16, s, t, st, ty);
+        }
+        uint32_t pos = blockAppend(vis, A.vis_count, s_wave, &s_base);
+        if (vis) A.vis_pairs[pos] = p;
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_eval(RenderArgs A) {
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint64_t total = *A.vis_count;
+    Tally ty;
+    for (uint64_t j = gid; j < total; j += nthreads) {
+        uint64_t p = A.vis_pairs[j];
+        pairEval<STATS>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), ty);
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+}
+
+}  // namespace ub
