@@ -3,24 +3,27 @@
 // renderPixel's connection loop (uengine/ubdptrenderer.cpp:103-149) reads every vertex of both
 // subpaths many times: vertex s of the light subpath for every t, vertex t of the eye subpath for
 // every s, and the pdf chains of all earlier vertices for every MIS weight. Gathering those from the
-// [field][slot][path] store one 8-byte word at a time saturates the vector L1 with pending misses.
-// Here a workgroup owns kTilePaths consecutive pixel-samples:
-//   1. the vertices of their eye and light subpaths are copied once from HBM into LDS with loads
-//      that run along the path index (contiguous in the store), as records of kVS doubles;
-//   2. the workgroup enumerates the connectable (s,t) pairs of its pixel-samples with a prefix sum
-//      in LDS and deals them out one pair per lane, so no lane waits for another lane's loop;
-//   3. a pair is evaluated entirely from LDS (only the shadow ray touches HBM: the tree);
-//   4. contributions to a pixel-sample's own pixel (t >= 2) are summed in LDS and reach the sum
-//      buffer as three atomics per pixel-sample; t == 1 splats go to the buffer directly.
+// [field][slot][path] store per pair fetches every vertex ~2.7 times and is bound by the number of
+// L1 misses the memory pipeline can keep in flight. Here a workgroup owns kTilePaths consecutive
+// pixel-samples and works in phases whose live state is small:
+//   A. stage    the vertices of their subpaths are copied ONCE from HBM into LDS, with loads that run
+//               along the path index (contiguous in the store), as records of kVS doubles;
+//   B. count    connectable vertices per subpath, prefix sum of the pair counts (one wave);
+//   C. visible  one pair per lane: pixel projection (t = 1), geometric-normal test, shadow ray;
+//               the surviving pairs are compacted into an LDS list (ballot + wave totals);
+//   D. evaluate one visible pair per lane, entirely from LDS: connection factor, MIS weight;
+//               contributions to the pixel-sample's own pixel (t >= 2) are summed in LDS;
+//   E. flush    three atomics per pixel-sample into the sum buffer; t = 1 splats went there directly.
 // Pixel-samples whose vertices do not fit the tile (very long subpaths) take the per-pair HBM path.
 #pragma once
 
 namespace ub {
 
-constexpr int kTilePaths = 32;   // pixel-samples per workgroup
-constexpr int kTileVerts = 288;  // staged vertices per workgroup (mean is ~6.5 per pixel-sample)
-constexpr int kVS = 25;          // doubles per staged vertex: 22 fields, packed (flags, object), 2 spare; odd stride
-constexpr int kVInts = 22;       //   spreads a field of consecutive vertices over the LDS banks
+constexpr int kTilePaths = 32;    // pixel-samples per workgroup
+constexpr int kTileVerts = 288;   // staged vertices per workgroup (mean is ~6.5 per pixel-sample)
+constexpr int kTilePairs = 768;   // pairs per round of phases C and D
+constexpr int kVS = 25;           // doubles per staged vertex: 22 fields, packed (flags, object), 2 spare; odd stride
+constexpr int kVInts = 22;        //   spreads a field of consecutive vertices over the LDS banks
 
 struct LdsSubpath {
     const double* base;  // staged vertex 0 of the subpath
@@ -54,22 +57,23 @@ DEV uint32_t nthSetBit(uint32_t m, uint32_t k) {
 }
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, 2) void k_connect_tile(RenderArgs A) {  // LDS allows two tiles per CU
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ double s_v[kTileVerts * kVS];
     __shared__ double s_I[kTilePaths * 3];
+    __shared__ uint32_t s_vis[kTilePairs];   // visible pairs of the round: p | s << 8 | t << 16
     __shared__ uint32_t s_nE[kTilePaths], s_nL[kTilePaths], s_ofs[kTilePaths], s_staged[kTilePaths];
     __shared__ uint32_t s_okE[kTilePaths], s_okL[kTilePaths], s_pre[kTilePaths + 1], s_max[2];
+    __shared__ uint32_t s_wave[kBlock / 64], s_nvis;
     const DScene& S = A.S;
     const uint32_t tid = threadIdx.x;
     const uint64_t N = A.E.n;
     const uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
     const uint64_t path0 = (uint64_t)blockIdx.x * kTilePaths;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
     Tally ty;
 
-    // 1. subpath lengths and the place of every pixel-sample's vertices in the tile (wave 0)
+    // ---- A0. subpath lengths and the place of every pixel-sample's vertices in the tile (wave 0)
     if (tid < 64) {
         uint32_t p = tid;
         uint64_t i = path0 + p;
@@ -89,10 +93,10 @@ __global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
     }
     __syncthreads();
 
-    // 2. stage: a row is (slot, field) of one subpath kind; 32 consecutive lanes read 32 consecutive paths
+    // ---- A. stage: a row is (slot, field) of one subpath kind; 32 consecutive lanes read 32 consecutive paths
     {
         const uint32_t p = tid & (kTilePaths - 1);
-        const uint32_t r0 = tid / kTilePaths;               // 8 rows in flight per workgroup
+        const uint32_t r0 = tid / kTilePaths;
         const uint64_t i = path0 + p;
         const bool staged = s_staged[p] != 0;
         const uint32_t nE = s_nE[p], nL = s_nL[p], ofs = s_ofs[p];
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
     }
     __syncthreads();
 
-    // 3. connectable vertices (exist, not specular) and the pair prefix sum (wave 0)
+    // ---- B. connectable vertices (exist, not specular) and the pair prefix sum (wave 0)
     if (tid < 64) {
         uint32_t p = tid;
         uint32_t okE = 0, okL = 0, cnt = 0;
@@ -146,56 +150,91 @@ __global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
     }
     __syncthreads();
 
-    // 4. one pair per lane, evaluated from LDS
     const uint32_t total = s_pre[kTilePaths];
-    for (uint32_t j = tid; j < total; j += kBlock) {
-        uint32_t p = 0;
+    for (uint32_t round0 = 0; round0 < total; round0 += kTilePairs) {
+        if (tid == 0) s_nvis = 0;
+        __syncthreads();
+        // ---- C. visibility, survivors compacted into s_vis
+        {
+            Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+            for (uint32_t it = 0; it < kTilePairs / kBlock; it++) {
+                uint32_t j = round0 + it * kBlock + tid;
+                bool vis = false;
+                uint32_t packed = 0;
+                if (j < total) {
+                    uint32_t p = 0;
 #pragma unroll
-        for (int step = kTilePaths / 2; step >= 1; step >>= 1)
-            if (s_pre[p + step] <= j) p += step;
-        uint32_t local = j - s_pre[p];
-        uint32_t okE = s_okE[p], okL = s_okL[p];
-        uint32_t cE = (uint32_t)__popc(okE);
-        uint32_t s = nthSetBit(okL, local / cE) + 1, t = nthSetBit(okE, local % cE) + 1;
-        LdsSubpath Ev{&s_v[s_ofs[p] * kVS]}, Lv{&s_v[(s_ofs[p] + s_nE[p]) * kVS]};
-        d3 lpos = Lv.ld3(F_POS, s - 1), epos = Ev.ld3(F_POS, t - 1);
-        uint32_t tx = 0, tyy = 0;
-        if (t == 1) {
-            if (!t1Pixel(S, lpos, epos, tx, tyy)) continue;
+                    for (int step = kTilePaths / 2; step >= 1; step >>= 1)
+                        if (s_pre[p + step] <= j) p += step;
+                    uint32_t local = j - s_pre[p];
+                    uint32_t okE = s_okE[p], okL = s_okL[p];
+                    uint32_t cE = (uint32_t)__popc(okE);
+                    uint32_t s = nthSetBit(okL, local / cE) + 1, t = nthSetBit(okE, local % cE) + 1;
+                    packed = p | (s << 8) | (t << 16);
+                    LdsSubpath Ev{&s_v[s_ofs[p] * kVS]}, Lv{&s_v[(s_ofs[p] + s_nE[p]) * kVS]};
+                    d3 lpos = Lv.ld3(F_POS, s - 1), epos = Ev.ld3(F_POS, t - 1);
+                    bool ok = true;
+                    if (t == 1) {
+                        uint32_t tx, tyy;
+                        ok = t1Pixel(S, lpos, epos, tx, tyy);
+                    }
+                    if (ok) {  // geometric-normal test of connectionFactor (:622-626), ahead of the shadow ray
+                        d3 ce = lpos - epos;
+                        ce = ce / sqrt(dot(ce, ce));
+                        ok = !((dot(ce, Ev.ld3(F_NG, t - 1)) <= 0) || (dot(-ce, Lv.ld3(F_NG, s - 1)) <= 0));
+                    }
+                    if (ok) vis = visible<STATS>(S, lpos, epos, st, ty);
+                }
+                unsigned long long m = __ballot(vis);
+                if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(m);
+                __syncthreads();
+                uint32_t pos = s_nvis + (uint32_t)__popcll(m & ((1ULL << (tid & 63)) - 1ULL));
+                for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
+                if (vis) s_vis[pos] = packed;
+                __syncthreads();
+                if (tid == 0) s_nvis += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+                __syncthreads();
+            }
+            if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
         }
-        {   // geometric-normal test of connectionFactor (:622-626), ahead of the shadow ray
-            d3 ce = lpos - epos;
-            ce = ce / sqrt(dot(ce, ce));
-            if ((dot(ce, Ev.ld3(F_NG, t - 1)) <= 0) || (dot(-ce, Lv.ld3(F_NG, s - 1)) <= 0)) continue;
+        // ---- D. evaluation of the visible pairs, from LDS
+        const uint32_t nvis = s_nvis;
+        for (uint32_t k = tid; k < nvis; k += kBlock) {
+            uint32_t packed = s_vis[k];
+            uint32_t p = packed & 0xff, s = (packed >> 8) & 0xff, t = packed >> 16;
+            LdsSubpath Ev{&s_v[s_ofs[p] * kVS]}, Lv{&s_v[(s_ofs[p] + s_nE[p]) * kVS]};
+            ConnVertex vl, ve;
+            loadConnLds(Lv, s - 1, vl);
+            loadConnLds(Ev, t - 1, ve);
+            d3 lprev = s > 1 ? Lv.ld3(F_POS, s - 2) : mk3(0, 0, 0);
+            d3 eprev = t > 1 ? Ev.ld3(F_POS, t - 2) : mk3(0, 0, 0);
+            d3 c;
+            double w;
+            if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
+                if (!connectLambert(S, Lv, Ev, 0, vl, ve, s, t, lprev, eprev, c, w)) continue;
+            } else {
+                if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) continue;
+                w = misWeight(S, Lv, Ev, 0, vl, ve, s, t, lprev, eprev);
+            }
+            d3 val = vl.a * ve.a * c * w;
+            if (STATS) ty.conn++;
+            if (t == 1) {
+                uint32_t tx = 0, tyy = 0;
+                if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) continue;
+                if (STATS) { ty.splat++; ty.fb++; }
+                fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, val);
+            } else {
+                atomicAdd(&s_I[3 * p], val.x);
+                atomicAdd(&s_I[3 * p + 1], val.y);
+                atomicAdd(&s_I[3 * p + 2], val.z);
+            }
         }
-        if (!visible<STATS>(S, lpos, epos, st, ty)) continue;
-        ConnVertex vl, ve;
-        loadConnLds(Lv, s - 1, vl);
-        loadConnLds(Ev, t - 1, ve);
-        d3 lprev = s > 1 ? Lv.ld3(F_POS, s - 2) : mk3(0, 0, 0);
-        d3 eprev = t > 1 ? Ev.ld3(F_POS, t - 2) : mk3(0, 0, 0);
-        d3 c;
-        double w;
-        if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
-            if (!connectLambert(S, Lv, Ev, 0, vl, ve, s, t, lprev, eprev, c, w)) continue;
-        } else {
-            if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) continue;
-            w = misWeight(S, Lv, Ev, 0, vl, ve, s, t, lprev, eprev);
-        }
-        d3 val = vl.a * ve.a * c * w;
-        if (STATS) ty.conn++;
-        if (t == 1) {
-            if (STATS) { ty.splat++; ty.fb++; }
-            fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, val);
-        } else {
-            atomicAdd(&s_I[3 * p], val.x);
-            atomicAdd(&s_I[3 * p + 1], val.y);
-            atomicAdd(&s_I[3 * p + 2], val.z);
-        }
+        __syncthreads();
     }
 
-    // 5. pixel-samples that did not fit the tile: per-pair evaluation straight from HBM
+    // ---- pixel-samples that did not fit the tile: per-pair evaluation straight from HBM
     if (tid < kTilePaths && !s_staged[tid] && (s_nE[tid] + s_nL[tid]) > 0) {
+        Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
         uint64_t i = path0 + tid;
         for (uint32_t s = 1; s <= s_nL[tid]; s++) {
             if (A.L.specular(s - 1, i)) continue;
@@ -204,10 +243,11 @@ __global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
                 connectPair<STATS>(A, i, s, t, st, ty);
             }
         }
+        if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
     }
     __syncthreads();
 
-    // 6. own-pixel sums of the tile -> sum buffer
+    // ---- E. own-pixel sums of the tile -> sum buffer
     if (tid < kTilePaths * 3) {
         uint32_t p = tid / 3, ch = tid % 3;
         double v = s_I[tid];
@@ -218,7 +258,6 @@ __global__ __launch_bounds__(kBlock) void k_connect_tile(RenderArgs A) {
         }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
-    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
 }  // namespace ub
