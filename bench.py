@@ -57,18 +57,28 @@ def measure_work(scene, params, device, passes, seed, accel, pipeline=0):
     # vertex records: the generation kernel writes the lens and the emitter vertex of every
     # pixel-sample, the bounce / tail / per-path kernels the rest (split by their share of closest-hit
     # rays); the connection stage reads every vertex once
-    writers = [k for k in s["kernels"] if k["name"] in ("k_wf_bounce", "k_wf_tail", "k_eye", "k_light")]
-    wrays = float(sum(k["closest_hit_rays"] for k in writers)) or 1.0
-    has_gen = any(k["name"] == "k_wf_gen" for k in s["kernels"])
+    # k_wf_shade pushes the vertices of the hits that k_wf_trace found, so its share is trace's rays
+    by_name = {k["name"]: k for k in s["kernels"]}
+    writer_rays = {}
+    for name in ("k_wf_bounce", "k_wf_tail", "k_eye", "k_light"):
+        if name in by_name:
+            writer_rays[name] = float(by_name[name]["closest_hit_rays"])
+    if "k_wf_shade" in by_name and "k_wf_trace" in by_name:
+        writer_rays["k_wf_shade"] = float(by_name["k_wf_trace"]["closest_hit_rays"])
+    wrays = sum(writer_rays.values()) or 1.0
+    has_gen = "k_wf_gen" in by_name
     rest = (ev + lv - 2 * ps) if has_gen else (ev + lv)
+    # the connection stage reads every vertex once; with the split pair kernels that read is charged
+    # to the evaluation kernel (the visibility kernel is charged its shadow rays and their traversal)
+    readers = ("k_connect", "k_pair_process", "k_pair_eval")
     for k in s["kernels"]:
         kk = dict(k)
-        if k["name"] in ("k_connect", "k_pair_process"):
+        if k["name"] in readers:
             kk["vertices"] = ev + lv
         elif k["name"] == "k_wf_gen":
             kk["vertices"] = 2 * ps
-        elif k["name"] in ("k_wf_bounce", "k_wf_tail", "k_eye", "k_light"):
-            kk["vertices"] = rest * k["closest_hit_rays"] / wrays
+        elif k["name"] in writer_rays:
+            kk["vertices"] = rest * writer_rays[k["name"]] / wrays
         else:
             kk["vertices"] = 0
         per_kernel[k["name"]] = algorithmic_bytes(kk) / ps
@@ -119,6 +129,8 @@ def main():
     ap.add_argument("--passes-in-flight", type=int, default=0)
     ap.add_argument("--dense-threshold", type=int, default=0,
                     help="lanes of a wave that must own an (s,t) pair for it to be connected in place (0 = default)")
+    ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
+    ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -157,7 +169,9 @@ def main():
     opt.accel = args.accel
     opt.pipeline = args.pipeline
     opt.passes_in_flight = args.passes_in_flight
-    opt.reserved[0] = args.dense_threshold
+    opt.dense_threshold = args.dense_threshold
+    opt.wavefront_depth = args.wavefront_depth
+    opt.streams = args.streams
     ctx = capi.Context(scene, params, opt, device)
     sum_dev = torch.zeros((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
 
@@ -181,8 +195,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.steps):
         first = s * pps * ngpu + rank
-        ctx.render_passes(first, pps, args.seed, pass_stride=ngpu)
-    ctx.read_sum_device(sum_dev.data_ptr())
+        ctx.enqueue_passes(first, pps, args.seed, pass_stride=ngpu)
+    ctx.read_sum_device(sum_dev.data_ptr())  # waits for the enqueued passes
     if dist is not None:
         dist.reduce(sum_dev, dst=0)
     sync_all()
@@ -219,7 +233,8 @@ def main():
             "config": {"workload": f"{args.config}: Cornell box, dielectric + perfect-mirror spheres, {W}x{H}",
                        "passes_per_step": pps, "spp_total": total_passes, "passes_per_gpu": args.steps * pps,
                        "accel": "lbvh" if args.accel == 0 else "linear", "pipeline": args.pipeline,
-                       "passes_in_flight": args.passes_in_flight or "auto", "partition": f"passes round-robin over {ngpu} GPU(s)"},
+                       "passes_in_flight": args.passes_in_flight or "auto", "streams": args.streams or "default",
+                       "wavefront_depth": args.wavefront_depth or "default", "partition": f"passes round-robin over {ngpu} GPU(s)"},
             "mrays_per_s": value * work["rays_per_pixel_sample"],
             "rays_per_pixel_sample": work["rays_per_pixel_sample"],
             "mean_radiance": [float(x) for x in (img.reshape(-1, 3).mean(0) / total_passes)],

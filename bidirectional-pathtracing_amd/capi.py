@@ -58,7 +58,8 @@ class SceneDesc(C.Structure):
 
 class Options(C.Structure):
     _fields_ = [("max_path_vertices", C.c_uint32), ("passes_in_flight", C.c_uint32), ("accel", C.c_uint32),
-                ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+                ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32), ("dense_threshold", C.c_uint32),
+                ("wavefront_depth", C.c_uint32), ("streams", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3)])
@@ -96,7 +97,7 @@ class Stats(C.Structure):
 # Every entry point include/ubdpt.h declares; tests check that the library exports all of them.
 EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
-    "ubdpt_render_passes", "ubdpt_request_stop", "ubdpt_read_sum", "ubdpt_read_sum_device", "ubdpt_upload_sum",
+    "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum", "ubdpt_read_sum_device", "ubdpt_upload_sum",
     "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
@@ -151,6 +152,8 @@ def load_library(path=None):
     lib.ubdpt_create.argtypes = [C.POINTER(SceneDesc), C.POINTER(RenderParams), C.POINTER(Options), C.c_int, C.POINTER(vp)]
     lib.ubdpt_destroy.argtypes = [vp]
     lib.ubdpt_render_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.ubdpt_enqueue_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.ubdpt_synchronize.argtypes = [vp]
     lib.ubdpt_request_stop.argtypes = [vp]
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
@@ -222,6 +225,15 @@ class Context:
         st = self.lib.ubdpt_render_passes(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
         _check(st, "ubdpt_render_passes", allow=(STOPPED,))
         return st, done.value
+
+    def enqueue_passes(self, first_pass, n_passes, seed, pass_stride=1):
+        done = C.c_uint32(0)
+        st = self.lib.ubdpt_enqueue_passes(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
+        _check(st, "ubdpt_enqueue_passes", allow=(STOPPED,))
+        return st, done.value
+
+    def synchronize(self):
+        _check(self.lib.ubdpt_synchronize(self.handle), "ubdpt_synchronize")
 
     def request_stop(self):
         _check(self.lib.ubdpt_request_stop(self.handle), "ubdpt_request_stop")

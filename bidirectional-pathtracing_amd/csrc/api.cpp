@@ -63,9 +63,9 @@ m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
     return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
 }
 
-enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_CONNECT_HYBRID, K_CONNECT_TILE, K_PAIR_PROCESS, K_PAIR_VISIBLE,
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_CONNECT_HYBRID, K_PAIR_PROCESS, K_PAIR_VISIBLE,
                 K_PAIR_EVAL, K_WF_GEN, K_WF_BOUNCE, K_WF_TRACE, K_WF_SHADE, K_WF_TAIL, K_INTERSECT, K_VISIBILITY, K_NUM };
-const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_connect_hybrid", "k_connect_tile",
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_connect_hybrid",
                                    "k_pair_process", "k_pair_visible", "k_pair_eval", "k_wf_gen", "k_wf_bounce", "k_wf_trace",
                                    "k_wf_shade", "k_wf_tail", "k_intersect_batch", "k_visibility_batch"};
 constexpr int kLastRenderKernel = K_WF_TAIL;
@@ -109,26 +109,33 @@ struct ubdpt_context {
     uint64_t npix = 0;
     double* d_fb = nullptr;       // planar
     double* d_staging = nullptr;  // interleaved, npix * 3
-    uint64_t cap_paths = 0;       // path slots allocated
+    uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
-    PathStore E{}, L{};
-    int32_t* d_ovf = nullptr;
+    uint32_t wf_depth = 6;        // bounces run as wavefront launches before the tail loop
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
-    int32_t* d_ovf_tile = nullptr;    // same, for the tiled connection kernel (8 lanes per pixel-sample)
-    uint64_t ovf_threads_tile = 0;
-    unsigned long long* d_counters = nullptr;
-    uint64_t* d_pairs = nullptr;
     unsigned long long pair_capacity = 0;
-    unsigned long long* d_pair_count = nullptr;
-    double* d_carry = nullptr;
-    int32_t* d_wf_hit_obj = nullptr;
-    uint32_t* d_wf_hit_face = nullptr;
-    double* d_wf_hit_duv = nullptr;
-    uint32_t* d_wf_hit_q = nullptr;
-    uint64_t* d_vis_pairs = nullptr;
-    uint32_t* d_vis_count = nullptr;
-    uint32_t* d_wf_trace_q = nullptr;
-    uint32_t* d_wf_count = nullptr;
+    // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
+    // lanes, so the narrow late stages of one batch (deep bounces, tail) overlap the wide early
+    // stages of the next. The sum buffer and the counters are shared (atomics).
+    struct BatchLane {
+        hipStream_t stream = nullptr;
+        PathStore E{}, L{};
+        int32_t* d_ovf = nullptr;
+        uint64_t* d_pairs = nullptr;
+        unsigned long long* d_pair_count = nullptr;
+        double* d_carry = nullptr;
+        double* d_wf_hit = nullptr;
+        uint32_t* d_wf_hit_q = nullptr;
+        uint64_t* d_vis_pairs = nullptr;
+        uint32_t* d_vis_count = nullptr;
+        uint32_t* d_wf_trace_q = nullptr;
+        uint32_t* d_wf_count = nullptr;
+    };
+    std::vector<BatchLane> lanes;
+    uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
+    bool work_pending = false;    // batches were enqueued and not yet waited for
+    double pending_since = 0;
+    unsigned long long* d_counters = nullptr;
 
     std::atomic<bool> stop{false};
     std::mutex mu;
@@ -143,7 +150,9 @@ struct ubdpt_context {
 
     hipError_t last_hip = hipSuccess;
 
-    void beginTimed(int kernel, double units) {
+    void beginTimed(int kernel, double units) { beginTimed(kernel, units, stream); }
+    void endTimed() { endTimed(stream); }
+    void beginTimed(int kernel, double units, hipStream_t stream) {
         TimedLaunch t;
         if (!event_pool.empty()) { t.start = event_pool.back().first; t.stop = event_pool.back().second; event_pool.pop_back(); }
         else { hipEventCreate(&t.start); hipEventCreate(&t.stop); }
@@ -151,7 +160,7 @@ struct ubdpt_context {
         hipEventRecord(t.start, stream);
         pending.push_back(t);
     }
-    void endTimed() { hipEventRecord(pending.back().stop, stream); }
+    void endTimed(hipStream_t stream) { hipEventRecord(pending.back().stop, stream); }
     void collectTimed() {  // call after the stream is synchronised
         for (auto& t : pending) {
             float ms = 0;
@@ -169,12 +178,14 @@ struct ubdpt_context {
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
-        hipFree(E.v); hipFree(E.object); hipFree(E.flags); hipFree(E.count);
-        hipFree(L.v); hipFree(L.object); hipFree(L.flags); hipFree(L.count);
-        hipFree(d_ovf); hipFree(d_ovf_tile); hipFree(d_counters); hipFree(d_pairs); hipFree(d_pair_count);
-        hipFree(d_carry); hipFree(d_wf_trace_q); hipFree(d_wf_count);
-        hipFree(d_wf_hit_obj); hipFree(d_wf_hit_face); hipFree(d_wf_hit_duv); hipFree(d_wf_hit_q); hipFree(d_vis_pairs);
-        hipFree(d_vis_count);
+        for (auto& b : lanes) {
+            if (b.stream) hipStreamSynchronize(b.stream);
+            hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
+            hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
+            hipFree(b.d_wf_hit_q); hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
+            if (b.stream) hipStreamDestroy(b.stream);
+        }
+        hipFree(d_counters);
         if (stream) hipStreamDestroy(stream);
     }
 };
@@ -186,9 +197,7 @@ namespace {
 
 int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv) {
     P.n = n; P.maxv = maxv;
-    HIPCK(c, hipMalloc((void**)&P.v, sizeof(double) * NUM_F * maxv * n));
-    HIPCK(c, hipMalloc((void**)&P.object, sizeof(int32_t) * maxv * n));
-    HIPCK(c, hipMalloc((void**)&P.flags, sizeof(int32_t) * maxv * n));
+    HIPCK(c, hipMalloc((void**)&P.v, sizeof(double) * kVertexDoubles * maxv * n));
     HIPCK(c, hipMalloc((void**)&P.count, sizeof(uint32_t) * n));
     return UBDPT_SUCCESS;
 }
@@ -410,6 +419,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
     double t0 = nowSeconds();
     c->device = device;
     if (options) c->opt = *options;
+    if (c->opt.pipeline > 3) { delete c; return UBDPT_INVALID_ARG; }
     if (c->opt.max_path_vertices == 0) c->opt.max_path_vertices = 32;
     if (c->opt.max_path_vertices < 2) c->opt.max_path_vertices = 2;
     if (c->opt.max_path_vertices > 255) c->opt.max_path_vertices = 255;
@@ -421,7 +431,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((st = flattenAndUpload(c, scene)) != UBDPT_SUCCESS) break;
         c->npix = params->img_res_x * params->img_res_y;
         // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
-        uint64_t per_path = (uint64_t)(sizeof(double) * NUM_F + 8) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8;
+        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8;
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
             uint64_t target = 1ull << 20;
@@ -432,33 +442,37 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         while (pif > 1 && per_path * c->npix * pif > (24ull << 30)) pif--;
         c->passes_in_flight = pif;
         c->cap_paths = c->npix * pif;
+        // the packed queue entries hold a subpath id in 29 bits
+        if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
+        uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 4) : 2;
+        c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 6;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
-        if ((st = allocStore(c, c->E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
-        if ((st = allocStore(c, c->L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
-        ck(hipMalloc((void**)&c->d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_threads));
-        c->ovf_threads_tile = ((c->cap_paths + 31) / 32) * 256;
-        ck(hipMalloc((void**)&c->d_ovf_tile, sizeof(int32_t) * kOverflowStack * c->ovf_threads_tile));
         c->pair_capacity = c->cap_paths * 24;
-        ck(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * c->pair_capacity));
-        ck(hipMalloc((void**)&c->d_pair_count, sizeof(unsigned long long)));
-        {
+        c->lanes.resize(nstreams);
+        for (auto& b : c->lanes) {
+            ck(hipStreamCreate(&b.stream));
+            if (st != UBDPT_SUCCESS) break;
+            if ((st = allocStore(c, b.E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
+            if ((st = allocStore(c, b.L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
             uint64_t n2 = 2 * c->cap_paths;
-            ck(hipMalloc((void**)&c->d_carry, sizeof(double) * 7 * n2));
-            ck(hipMalloc((void**)&c->d_wf_hit_obj, sizeof(int32_t) * n2));
-            ck(hipMalloc((void**)&c->d_wf_hit_face, sizeof(uint32_t) * n2));
-            ck(hipMalloc((void**)&c->d_wf_hit_duv, sizeof(double) * 3 * n2));
+            ck(hipMalloc((void**)&b.d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_threads));
+            ck(hipMalloc((void**)&b.d_pairs, sizeof(uint64_t) * c->pair_capacity));
+            ck(hipMalloc((void**)&b.d_pair_count, sizeof(unsigned long long)));
+            ck(hipMalloc((void**)&b.d_carry, sizeof(double) * kCarryDoubles * n2));
+            ck(hipMalloc((void**)&b.d_wf_hit, sizeof(double) * kHitDoubles * n2));
             // every 256-chunk is padded to whole waves: at most 63 extra entries per chunk
-            ck(hipMalloc((void**)&c->d_wf_hit_q, sizeof(uint32_t) * (n2 + 64 * (n2 / 256 + 2))));
-            ck(hipMalloc((void**)&c->d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
-            ck(hipMalloc((void**)&c->d_vis_count, sizeof(uint32_t)));
-            ck(hipMalloc((void**)&c->d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
-            ck(hipMalloc((void**)&c->d_wf_count, sizeof(uint32_t) * 16 * (kWfDepth + 2)));
+            ck(hipMalloc((void**)&b.d_wf_hit_q, sizeof(uint32_t) * (n2 + 64 * (n2 / 256 + 2))));
+            ck(hipMalloc((void**)&b.d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
+            ck(hipMalloc((void**)&b.d_vis_count, sizeof(uint32_t)));
+            ck(hipMalloc((void**)&b.d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
+            ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
         }
+        if (st != UBDPT_SUCCESS) break;
         ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
@@ -481,36 +495,55 @@ int ubdpt_destroy(ubdpt_context* c) {
     return UBDPT_SUCCESS;
 }
 
-int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
-                        uint32_t* passes_done) {
+// Waits for every enqueued batch, then folds the event timings and the device counters into the
+// statistics. Called with the context mutex held.
+static int finishPending(ubdpt_context* c) {
+    if (!c->work_pending) return UBDPT_SUCCESS;
+    for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
+    c->work_pending = false;
+    c->collectTimed();
+    int fc = fetchCounters(c);
+    if (fc != UBDPT_SUCCESS) return fc;
+    c->stats.render_seconds += nowSeconds() - c->pending_since;
+    if (c->stack_overflows) {
+        fprintf(stderr, "ubdpt: traversal stack overflow on %llu rays\n", (unsigned long long)c->stack_overflows);
+        return UBDPT_ERROR;
+    }
+    return UBDPT_SUCCESS;
+}
+
+static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                        uint32_t* passes_done, bool wait) {
     if (passes_done) *passes_done = 0;
     if (!c) return UBDPT_INVALID_ARG;
     if (pass_stride == 0) pass_stride = 1;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     c->stop = false;  // UBDPTRenderer::renderPass resets m_stop (ubdptrenderer.cpp:37)
-    double t0 = nowSeconds();
+    if (!c->work_pending) { c->work_pending = true; c->pending_since = nowSeconds(); }
     bool stats = c->opt.collect_stats != 0;
     uint32_t done = 0;
     int status = UBDPT_SUCCESS;
+    uint64_t& batch = c->next_batch;
     while (done < n_passes) {
         if (c->stop.load()) { status = UBDPT_STOPPED; break; }
         uint32_t nb = n_passes - done;
         if (nb > c->passes_in_flight) nb = c->passes_in_flight;
+        ubdpt_context::BatchLane& B = c->lanes[batch % c->lanes.size()];
+        hipStream_t sm = B.stream;
         RenderArgs A;
         A.S = c->S;
-        A.E = c->E; A.L = c->L;
+        A.E = B.E; A.L = B.L;
         A.E.n = A.L.n = c->npix * nb;
         A.fb = c->d_fb;
         A.first_pass = first_pass + (uint64_t)done * pass_stride;
         A.pass_stride = pass_stride;
         A.seed = seed;
-        A.ovf = c->d_ovf; A.ovf_stride = A.E.n;
+        A.ovf = B.d_ovf; A.ovf_stride = A.E.n;
         A.counters = c->d_counters;
-        A.pairs = c->d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = c->d_pair_count;
-        A.carry = c->d_carry; A.wf_trace_q = c->d_wf_trace_q; A.wf_count = c->d_wf_count;
-        A.wf_hit_obj = c->d_wf_hit_obj; A.wf_hit_face = c->d_wf_hit_face; A.wf_hit_duv = c->d_wf_hit_duv;
-        A.wf_hit_q = c->d_wf_hit_q; A.vis_pairs = c->d_vis_pairs; A.vis_count = c->d_vis_count;
+        A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
+        A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
+        A.wf_hit = B.d_wf_hit; A.wf_hit_q = B.d_wf_hit_q; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
@@ -519,85 +552,86 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         //           1 = per-path subpath kernels + per-path connection loop
         //           2 = per-path subpath kernels + global pair queue, one kernel per pair
         //           3 = wavefront with fused trace+shade bounce kernel + in-place dense / queued sparse pairs
-        //           4 = wavefront small kernels + LDS-tiled connection kernel
         const uint32_t pl = c->opt.pipeline;
-        if (pl == 0 || pl == 3 || pl == 4) {
-            HIPCK(c, hipMemsetAsync(c->d_wf_count, 0, sizeof(uint32_t) * 16 * (kWfDepth + 2), c->stream));
+        const uint32_t D = c->wf_depth;
+        auto run = [&](int kernel, double u, auto&& launch) {
+            A.counters = c->d_counters + kernel * kNumCounters;
+            c->beginTimed(kernel, u, sm); launch(); c->endTimed(sm);
+        };
+        if (pl == 0 || pl == 3) {
+            HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
             A.ovf_stride = pstride;
-            A.counters = c->d_counters + K_WF_GEN * kNumCounters;
-            c->beginTimed(K_WF_GEN, 2 * units); launchWfGen(A, stats, c->stream); c->endTimed();
-            for (uint32_t d = 0; d < kWfDepth; d++) {
+            run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
+            for (uint32_t d = 0; d < D; d++) {
                 if (pl == 3) {
-                    A.counters = c->d_counters + K_WF_BOUNCE * kNumCounters;
-                    c->beginTimed(K_WF_BOUNCE, d == 0 ? units : 0); launchWfBounce(A, d, pblocks, stats, c->stream); c->endTimed();
+                    run(K_WF_BOUNCE, d == 0 ? units : 0, [&] { launchWfBounce(A, d, pblocks, stats, sm); });
                 } else {
-                    A.counters = c->d_counters + K_WF_TRACE * kNumCounters;
-                    c->beginTimed(K_WF_TRACE, d == 0 ? units : 0); launchWfTrace(A, d, pblocks, stats, c->stream); c->endTimed();
-                    A.counters = c->d_counters + K_WF_SHADE * kNumCounters;
-                    c->beginTimed(K_WF_SHADE, d == 0 ? units : 0); launchWfShade(A, d, pblocks, stats, c->stream); c->endTimed();
+                    run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, pblocks, stats, sm); });
+                    run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
                 }
             }
-            A.counters = c->d_counters + K_WF_TAIL * kNumCounters;
-            c->beginTimed(K_WF_TAIL, units); launchWfTail(A, kWfDepth, pblocks, stats, c->stream); c->endTimed();
+            run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
         } else {
             A.ovf_stride = A.E.n;
-            A.counters = c->d_counters + K_EYE * kNumCounters;
-            c->beginTimed(K_EYE, units);     launchEye(A, stats, c->stream);     c->endTimed();
-            A.counters = c->d_counters + K_LIGHT * kNumCounters;
-            c->beginTimed(K_LIGHT, units);   launchLight(A, stats, c->stream);   c->endTimed();
+            run(K_EYE, units, [&] { launchEye(A, stats, sm); });
+            run(K_LIGHT, units, [&] { launchLight(A, stats, sm); });
         }
-        if (pl == 4) {
-            // one workgroup per 32 pixel-samples, 8 lanes per pixel-sample: lane ids stay below 8 * n
-            A.ovf_stride = c->ovf_threads_tile;
-            A.ovf = c->d_ovf_tile;
-            A.counters = c->d_counters + K_CONNECT_TILE * kNumCounters;
-            c->beginTimed(K_CONNECT_TILE, units); launchConnectTile(A, stats, c->stream); c->endTimed();
-            A.ovf = c->d_ovf;
-        } else if (pl == 1) {
+        if (pl == 1) {
             A.ovf_stride = A.E.n;
-            A.counters = c->d_counters + K_CONNECT * kNumCounters;
-            c->beginTimed(K_CONNECT, units); launchConnect(A, stats, c->stream); c->endTimed();
+            run(K_CONNECT, units, [&] { launchConnect(A, stats, sm); });
         } else {
-            HIPCK(c, hipMemsetAsync(c->d_pair_count, 0, sizeof(unsigned long long), c->stream));
+            HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
             A.ovf_stride = A.E.n;
             if (pl == 3) {
-                uint32_t thr = c->opt.reserved[0] ? c->opt.reserved[0] : 40;
-                A.counters = c->d_counters + K_CONNECT_HYBRID * kNumCounters;
-                c->beginTimed(K_CONNECT_HYBRID, units); launchConnectHybrid(A, thr, stats, c->stream); c->endTimed();
+                uint32_t thr = c->opt.dense_threshold ? c->opt.dense_threshold : 40;
+                run(K_CONNECT_HYBRID, units, [&] { launchConnectHybrid(A, thr, stats, sm); });
             } else {
-                A.counters = c->d_counters + K_PAIR_ENUM * kNumCounters;
-                c->beginTimed(K_PAIR_ENUM, units); launchPairEnum(A, stats, c->stream); c->endTimed();
+                run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
             }
             A.ovf_stride = pstride;
             if (pl == 0) {
-                HIPCK(c, hipMemsetAsync(c->d_vis_count, 0, sizeof(uint32_t), c->stream));
-                A.counters = c->d_counters + K_PAIR_VISIBLE * kNumCounters;
-                c->beginTimed(K_PAIR_VISIBLE, units); launchPairVisible(A, pblocks, stats, c->stream); c->endTimed();
-                A.counters = c->d_counters + K_PAIR_EVAL * kNumCounters;
-                c->beginTimed(K_PAIR_EVAL, units); launchPairEval(A, pblocks, stats, c->stream); c->endTimed();
+                HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
+                run(K_PAIR_VISIBLE, units, [&] { launchPairVisible(A, pblocks, stats, sm); });
+                run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
             } else {
-                A.counters = c->d_counters + K_PAIR_PROCESS * kNumCounters;
-                c->beginTimed(K_PAIR_PROCESS, units); launchPairProcess(A, pblocks, stats, c->stream); c->endTimed();
+                run(K_PAIR_PROCESS, units, [&] { launchPairProcess(A, pblocks, stats, sm); });
             }
         }
         HIPCK(c, hipGetLastError());
         done += nb;
-        // keep at most a few batches queued so that a stop request is honoured promptly
-        if ((done / c->passes_in_flight) % 4 == 0) HIPCK(c, hipStreamSynchronize(c->stream));
+        batch++;
+        // keep at most a few batches queued per lane so that a stop request is honoured promptly
+        if (batch % (4 * c->lanes.size()) == 0)
+        {
+            for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
+            c->collectTimed();
+        }
     }
-    HIPCK(c, hipStreamSynchronize(c->stream));
-    c->collectTimed();
-    int fc = fetchCounters(c);
-    if (fc != UBDPT_SUCCESS) return fc;
     c->stats.passes += done;
     c->stats.pixel_samples += (uint64_t)done * c->npix;
-    c->stats.render_seconds += nowSeconds() - t0;
     if (passes_done) *passes_done = done;
-    if (c->stack_overflows) {
-        fprintf(stderr, "ubdpt: traversal stack overflow on %llu rays\n", (unsigned long long)c->stack_overflows);
-        return UBDPT_ERROR;
+    if (wait) {
+        int fs = finishPending(c);
+        if (fs != UBDPT_SUCCESS) return fs;
     }
     return status;
+}
+
+int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                        uint32_t* passes_done) {
+    return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_done, true);
+}
+
+int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                         uint32_t* passes_enqueued) {
+    return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_enqueued, false);
+}
+
+int ubdpt_synchronize(ubdpt_context* c) {
+    if (!c) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    return finishPending(c);
 }
 
 int ubdpt_request_stop(ubdpt_context* c) {
@@ -610,6 +644,7 @@ int ubdpt_read_sum_device(ubdpt_context* c, double* device_rgb) {
     if (!c || !device_rgb) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     launchInterleave(c->d_fb, c->npix, device_rgb, c->stream);
     HIPCK(c, hipGetLastError());
     HIPCK(c, hipStreamSynchronize(c->stream));
@@ -620,6 +655,7 @@ int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
     if (!c || !rgb) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     launchInterleave(c->d_fb, c->npix, c->d_staging, c->stream);
     HIPCK(c, hipGetLastError());
     if (!add_into) {
@@ -638,6 +674,7 @@ int ubdpt_upload_sum(ubdpt_context* c, const double* rgb) {
     if (!c) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     if (!rgb) {
         HIPCK(c, hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
     } else {
@@ -653,6 +690,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
     if (!c || (n && (!rays || !hits))) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     size_t chunk = (size_t)c->cap_paths;
     ubdpt_ray* d_rays = nullptr;
     ubdpt_hit* d_hits = nullptr;
@@ -666,7 +704,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
         hipError_t e = hipMemcpyAsync(d_rays, rays + off, sizeof(ubdpt_ray) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_INTERSECT, (double)k);
-            launchIntersectBatch(c->S, d_rays, k, d_hits, c->d_ovf, k, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
+            launchIntersectBatch(c->S, d_rays, k, d_hits, c->lanes[0].d_ovf, k, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -685,6 +723,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
     if (!c || (n && (!segs || !visible))) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     if (n == 0) return UBDPT_SUCCESS;
     size_t chunk = (size_t)c->cap_paths;
     size_t m = n < chunk ? n : chunk;
@@ -698,7 +737,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
         hipError_t e = hipMemcpyAsync(d_segs, segs + off, sizeof(ubdpt_segment) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_VISIBILITY, (double)k);
-            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->d_ovf, k, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
+            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->lanes[0].d_ovf, k, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -717,6 +756,7 @@ static int bsdfBatch(ubdpt_context* c, int mode, const ubdpt_bsdf_query* q, size
     if (!c || (n && (!q || !r))) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     if (n == 0) return UBDPT_SUCCESS;
     ubdpt_bsdf_query* dq = nullptr;
     ubdpt_bsdf_result* dr = nullptr;
@@ -756,6 +796,7 @@ int ubdpt_get_camera_info(ubdpt_context* c, double view[16], double inv_view[16]
 int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
     if (!c || !out) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
+    if (c->work_pending) { hipSetDevice(c->device); int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     *out = c->stats;
     out->num_kernel_stats = 0;
     for (int k = 0; k < K_NUM && out->num_kernel_stats < UBDPT_MAX_KERNEL_STATS; k++) {
@@ -774,6 +815,7 @@ int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
 int ubdpt_reset_stats(ubdpt_context* c) {
     if (!c) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
+    if (c->work_pending) { hipSetDevice(c->device); int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
     double build = c->stats.build_seconds;
     memset(&c->stats, 0, sizeof(c->stats));
     c->stats.build_seconds = build;

@@ -1,8 +1,12 @@
 // paths.h — path-vertex storage in HBM and the BDPT measurement routines that read it.
 //
-// Vertex storage is a structure of arrays indexed [field][slot][path]: consecutive lanes (paths)
-// touch consecutive 8-byte words, so every vertex field access of a wave is one coalesced 512-byte
-// transaction, whatever slot the wave is working on. A vertex is UPathVertex
+// Vertex storage is an array of 192-byte records (24 doubles, three 64-byte lines). Subpaths die at
+// different depths, so a layout with one plane per field would leave the planes of the deeper slots
+// sparsely used, and every 8-byte access of a lone survivor would still fetch a whole 64-byte line
+// from HBM; with one record per vertex every fetched line is data of the vertex that asked for it.
+// The fields are grouped by consumer: line 0 holds what the ray tracing stages and the MIS walks
+// read (position, the two area pdfs, object / flags, texture coordinates), line 1 the normals,
+// line 2 the rest of the shading frame and the throughput. A vertex is UPathVertex
 // (uengine/ubdptrenderer.h:9-24) minus the two 128-byte matrices and the shared_ptrs, which are
 // replaced by the object index and the lobe id.
 #pragma once
@@ -11,17 +15,31 @@
 
 namespace ub {
 
-enum { F_POS = 0, F_NG = 3, F_NS = 6, F_TS = 9, F_BS = 12, F_A = 15, F_PL = 18, F_PE = 19, F_U = 20, F_V = 21, NUM_F = 22 };
+enum { F_POS = 0, F_PL = 3, F_PE = 4, F_U = 5, F_V = 6, F_OBJFLAGS = 7, F_NG = 8, F_NS = 11, F_TS = 14, F_BS = 17, F_A = 20,
+       kVertexDoubles = 24 };
+
+// The count word of a subpath: bits 0..7 = vertices stored, bit 8 + k = vertex k is specular
+// (k < kMaskedVertices; later vertices are looked up in their records).
+constexpr uint32_t kMaskedVertices = 24;
+DEV uint32_t specularBit(uint32_t k, bool specular) { return (specular && k < kMaskedVertices) ? (1u << (8 + k)) : 0u; }
 
 struct PathStore {
-    double* v;        // [NUM_F][maxv][n]
-    int32_t* object;  // [maxv][n]
-    int32_t* flags;   // [maxv][n]  bits 0..7 = lobe + 1, bit 8 = specular
-    uint32_t* count;  // [n] vertices stored
+    double* v;        // records of kVertexDoubles doubles
+    uint32_t* count;  // [n] count word per subpath
     uint64_t n;
     uint32_t maxv;
 
-    DEV uint64_t at(int f, uint32_t slot, uint64_t i) const { return ((uint64_t)f * maxv + slot) * n + i; }
+#ifdef UBDPT_PATH_MAJOR
+    DEV uint64_t rec(uint32_t slot, uint64_t i) const { return (i * maxv + slot) * kVertexDoubles; }
+#else
+    DEV uint64_t rec(uint32_t slot, uint64_t i) const { return ((uint64_t)slot * n + i) * kVertexDoubles; }
+#endif
+    DEV uint64_t at(int f, uint32_t slot, uint64_t i) const { return rec(slot, i) + (uint64_t)f; }
+    // object index and flags (bits 0..7 = lobe + 1, bit 8 = specular) share one 8-byte field
+    DEV int32_t* oflag(uint32_t slot, uint64_t i) const { return (int32_t*)(v + rec(slot, i) + F_OBJFLAGS); }
+    DEV int32_t obj(uint32_t slot, uint64_t i) const { return oflag(slot, i)[0]; }
+    DEV int32_t flg(uint32_t slot, uint64_t i) const { return oflag(slot, i)[1]; }
+    DEV void setObjFlags(uint32_t slot, uint64_t i, int32_t o, int32_t f) const { int32_t* p = oflag(slot, i); p[0] = o; p[1] = f; }
     DEV double ld(int f, uint32_t slot, uint64_t i) const { return v[at(f, slot, i)]; }
     DEV void st(int f, uint32_t slot, uint64_t i, double x) const { v[at(f, slot, i)] = x; }
     DEV d3 ld3(int f, uint32_t slot, uint64_t i) const {
@@ -30,9 +48,12 @@ struct PathStore {
     DEV void st3(int f, uint32_t slot, uint64_t i, d3 x) const {
         v[at(f, slot, i)] = x.x; v[at(f + 1, slot, i)] = x.y; v[at(f + 2, slot, i)] = x.z;
     }
-    DEV int32_t obj(uint32_t slot, uint64_t i) const { return object[(uint64_t)slot * n + i]; }
-    DEV int32_t flg(uint32_t slot, uint64_t i) const { return flags[(uint64_t)slot * n + i]; }
     DEV bool specular(uint32_t slot, uint64_t i) const { return (flg(slot, i) >> 8) & 1; }
+    DEV uint32_t cnt(uint64_t i) const { return count[i] & 0xffu; }
+    // may vertex k of subpath i (count word `meta`) be connected, i.e. is it not specular?
+    DEV bool connectable(uint32_t meta, uint32_t k, uint64_t i) const {
+        return k < kMaskedVertices ? !((meta >> (8 + k)) & 1u) : !specular(k, i);
+    }
     DEV int lobe(uint32_t slot, uint64_t i) const { return (flg(slot, i) & 0xff) - 1; }
 };
 
@@ -49,8 +70,7 @@ DEV void storeVertex(const PathStore& P, uint32_t slot, uint64_t i, const Vertex
     P.st3(F_TS, slot, i, x.sp.Ts);   P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
     P.st(F_PL, slot, i, x.p_light_A); P.st(F_PE, slot, i, x.p_eye_A);
     P.st(F_U, slot, i, x.sp.tex_u);   P.st(F_V, slot, i, x.sp.tex_v);
-    P.object[(uint64_t)slot * P.n + i] = x.sp.object;
-    P.flags[(uint64_t)slot * P.n + i] = ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0);
+    P.setObjFlags(slot, i, x.sp.object, ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0));
 }
 
 // The few fields of the last stored vertex that the subpath loop keeps in registers.

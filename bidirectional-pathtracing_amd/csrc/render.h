@@ -20,10 +20,8 @@ struct RenderArgs {
     unsigned long long pair_capacity;
     unsigned long long* pair_count;   // device counter, zeroed before every batch
     // wavefront subpath generation (wavefront.h); subpath id in [0, 2n)
-    double* carry;           // [7][2n]: ray direction, BSDF value, pdf of the last scattering
-    int32_t* wf_hit_obj;     // [2n] closest hit found by k_wf_trace, indexed by subpath id
-    uint32_t* wf_hit_face;   // [2n]
-    double* wf_hit_duv;      // [3][2n]
+    double* carry;           // [2n][kCarryDoubles]: ray direction, BSDF value, pdf of the last scattering
+    double* wf_hit;          // [2n][kHitDoubles]: d, u, v, (object | face << 32) of the closest hit found by k_wf_trace
     uint32_t* wf_hit_q;      // hit queue: id | region << 29, chunks padded to whole waves with 0xffffffff
     uint64_t* vis_pairs;     // connection pairs that passed the shadow ray
     uint32_t* vis_count;
@@ -31,7 +29,10 @@ struct RenderArgs {
     uint32_t* wf_count;      // [depth][16] queue lengths ([d][0] is used), zeroed before every batch
 };
 
-constexpr uint32_t kWfDepth = 6;  // bounces run as wavefront launches before the tail loop takes over
+constexpr uint32_t kMaxWfDepth = 30;  // most bounces that can run as wavefront launches before the tail loop takes over
+constexpr int kWfQStride = 16;        // counters per depth: [0] trace queue length, [1] hit queue length
+constexpr int kCarryDoubles = 8;      // one 64-byte line per subpath
+constexpr int kHitDoubles = 4;        // half a line per subpath
 void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
 void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
@@ -47,7 +48,6 @@ void launchLight(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s);
 void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool stats, hipStream_t s);
-void launchConnectTile(const RenderArgs& A, bool stats, hipStream_t s);
 void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);

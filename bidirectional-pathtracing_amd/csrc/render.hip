@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
     lens.p_light_A = 0;
     lens.specular = false;
     storeVertex(E, 0, gid, lens);
-    uint32_t n = 1;
+    uint32_t n = 1, smask = 0;
 
     d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
     d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
         finishVertex(obj, nv, dirT);
         I = I + s0sample(S, E, gid, n, cur, prev_specular, nv);
         storeVertex(E, n, gid, nv);
+        smask |= specularBit(n, nv.specular);
         n++;
         // the pushed vertex becomes curr, the old curr becomes prev
         prev_pos = cur.pos; prev_Ns = cur.Ns; prev_specular = cur.specular;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
             E.st(F_PL, n - 2, gid, q * p_psa * G_prev);
         }
     }
-    E.count[gid] = n;
+    E.count[gid] = n | smask;
     if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
     Rng rng{pathKey(A.seed, pass, pixel), STREAM_LIGHT};
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
     Tally ty;
-    uint32_t n = 0;
+    uint32_t n = 0, smask = 0;
 
     if (S.num_emitters > 0) {
         // emitter choice by cumulative probability (:413-428)
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
                 break;
             finishVertex(obj, nv, dT);
             storeVertex(L, n, gid, nv);
+            smask |= specularBit(n, nv.specular);
             n++;
             prev_pos = cur.pos; prev_Ns = cur.Ns;
             cur.pos = nv.sp.pos; cur.Ns = nv.sp.Ns; cur.specular = nv.specular;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
             }
         }
     }
-    L.count[gid] = n;
+    L.count[gid] = n | smask;
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
     Tally ty;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
-    uint32_t nE = E.count[gid], nL = L.count[gid];
+    uint32_t nE = E.cnt(gid), nL = L.cnt(gid);
     if (STATS) { Tally t0; flushTally(t0, A.counters, nE, nL); }
     d3 I = mk3(0, 0, 0);
     d3 lens_pos = E.ld3(F_POS, 0, gid);
@@ -529,33 +531,46 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
         fbAdd(A.fb, npix, i % npix, vl.a * ve.a * c * w);
 }
 
+// One lane per pixel-sample: appends its connectable (s,t) pairs to the pair queue. The specular
+// bits of the first kMaskedVertices vertices travel in the subpath's count word, so the common case
+// reads two words per pixel-sample; queue space is reserved with one atomic per workgroup.
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ unsigned long long s_base;
+    const uint32_t tid = threadIdx.x;
+    uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
     bool active = gid < A.E.n;
     const PathStore& E = A.E;
     const PathStore& L = A.L;
-    uint32_t nE = 0, nL = 0, cE = 0, cL = 0;
+    uint32_t mE = 0, mL = 0, nE = 0, nL = 0, cE = 0, cL = 0;
     if (active) {
-        nE = E.count[gid]; nL = L.count[gid];
-        for (uint32_t t = 0; t < nE; t++) cE += E.specular(t, gid) ? 0u : 1u;
-        for (uint32_t s = 0; s < nL; s++) cL += L.specular(s, gid) ? 0u : 1u;
+        mE = E.count[gid]; mL = L.count[gid];
+        nE = mE & 0xff; nL = mL & 0xff;
+        for (uint32_t t = 0; t < nE; t++) cE += E.connectable(mE, t, gid) ? 1u : 0u;
+        for (uint32_t s = 0; s < nL; s++) cL += L.connectable(mL, s, gid) ? 1u : 0u;
     }
     uint32_t cnt = cE * cL;
     if (STATS && active) { Tally t0; flushTally(t0, A.counters, nE, nL); }
     uint32_t incl = waveInclusiveScan(cnt);
-    uint32_t total = __shfl(incl, 63, 64);
-    unsigned long long base = 0;
-    if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(A.pair_count, (unsigned long long)total);
-    base = __shfl(base, 0, 64);
+    if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long tot = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) tot += s_wave[w];
+        s_base = tot ? atomicAdd(A.pair_count, tot) : 0ULL;
+    }
+    __syncthreads();
     if (!cnt) return;
-    unsigned long long pos = base + (incl - cnt);
+    unsigned long long pos = s_base + (incl - cnt);
+    for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
     if (pos + cnt <= A.pair_capacity) {
         for (uint32_t s = 1; s <= nL; s++) {
-            if (L.specular(s - 1, gid)) continue;
+            if (!L.connectable(mL, s - 1, gid)) continue;
             for (uint32_t t = 1; t <= nE; t++) {
-                if (E.specular(t - 1, gid)) continue;
+                if (!E.connectable(mE, t - 1, gid)) continue;
                 A.pairs[pos++] = packPair(gid, s, t);
             }
         }
@@ -566,9 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
         Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
         Tally ty;
         for (uint32_t s = 1; s <= nL; s++) {
-            if (L.specular(s - 1, gid)) continue;
+            if (!L.connectable(mL, s - 1, gid)) continue;
             for (uint32_t t = 1; t <= nE; t++) {
-                if (E.specular(t - 1, gid)) continue;
+                if (!E.connectable(mE, t - 1, gid)) continue;
                 connectPair<STATS>(A, gid, s, t, st, ty);
             }
         }
@@ -626,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_connect_hybrid(RenderArgs A, uint32_
     // than 64 vertices keep their first 64 here, the rest is handled by the per-lane loop below
     unsigned long long okE = 0, okL = 0;
     if (active) {
-        nE = E.count[gid]; nL = L.count[gid];
+        nE = E.cnt(gid); nL = L.cnt(gid);
         for (uint32_t t = 0; t < nE && t < 64; t++) okE |= E.specular(t, gid) ? 0ULL : (1ULL << t);
         for (uint32_t s = 0; s < nL && s < 64; s++) okL |= L.specular(s, gid) ? 0ULL : (1ULL << s);
     }
@@ -681,7 +696,6 @@ __global__ __launch_bounds__(kBlock) void k_connect_hybrid(RenderArgs A, uint32_
 }
 
 }  // namespace ub
-#include "connect_tile.h"
 #include "wavefront_split.h"
 namespace ub {
 
@@ -836,11 +850,6 @@ void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStre
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_eval<false>, dim3(blocks), dim3(kBlock), 0, s, A);
-}
-void launchConnectTile(const RenderArgs& A, bool stats, hipStream_t s) {
-    unsigned g = (unsigned)((A.E.n + kTilePaths - 1) / kTilePaths);
-    if (stats) hipLaunchKernelGGL(k_connect_tile<true>, dim3(g), dim3(kBlock), 0, s, A);
-    else hipLaunchKernelGGL(k_connect_tile<false>, dim3(g), dim3(kBlock), 0, s, A);
 }
 void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_process<true>, dim3(blocks), dim3(kBlock), 0, s, A);

@@ -13,7 +13,7 @@
 //                    sampling, vertex push, next ray;
 //                (4) survivors are appended to the next queue: ballot per wave, ONE global atomic
 //                    per chunk.
-//   k_wf_tail    after kWfDepth bounces the few survivors (long specular chains) finish in a per-lane loop
+//   k_wf_tail    after the wavefront bounces the few survivors (long specular chains) finish in a per-lane loop
 //
 // Subpath id: [0, N) are the eye subpaths, [N, 2N) the light subpaths of the batch's N pixel-samples.
 #pragma once
@@ -27,16 +27,31 @@ struct Carry {  // what a subpath keeps between two bounces besides its stored v
 };
 
 DEV void loadCarry(const RenderArgs& A, uint64_t id, Carry& c) {
-    uint64_t n2 = 2 * A.E.n;
-    c.dir = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
-    c.fs = mk3(A.carry[3 * n2 + id], A.carry[4 * n2 + id], A.carry[5 * n2 + id]);
-    c.p_psa = A.carry[6 * n2 + id];
+    const double* p = A.carry + id * kCarryDoubles;
+    c.dir = mk3(p[0], p[1], p[2]);
+    c.fs = mk3(p[3], p[4], p[5]);
+    c.p_psa = p[6];
+}
+DEV d3 loadCarryDir(const RenderArgs& A, uint64_t id) {
+    const double* p = A.carry + id * kCarryDoubles;
+    return mk3(p[0], p[1], p[2]);
 }
 DEV void storeCarry(const RenderArgs& A, uint64_t id, const Carry& c) {
-    uint64_t n2 = 2 * A.E.n;
-    A.carry[id] = c.dir.x; A.carry[n2 + id] = c.dir.y; A.carry[2 * n2 + id] = c.dir.z;
-    A.carry[3 * n2 + id] = c.fs.x; A.carry[4 * n2 + id] = c.fs.y; A.carry[5 * n2 + id] = c.fs.z;
-    A.carry[6 * n2 + id] = c.p_psa;
+    double* p = A.carry + id * kCarryDoubles;
+    p[0] = c.dir.x; p[1] = c.dir.y; p[2] = c.dir.z;
+    p[3] = c.fs.x; p[4] = c.fs.y; p[5] = c.fs.z;
+    p[6] = c.p_psa;
+}
+DEV void storeHit(const RenderArgs& A, uint64_t id, const Closest& h) {
+    double* p = A.wf_hit + id * kHitDoubles;
+    p[0] = h.d; p[1] = h.u; p[2] = h.v;
+    p[3] = __longlong_as_double((long long)(((unsigned long long)h.face << 32) | (uint32_t)h.object));
+}
+DEV void loadHit(const RenderArgs& A, uint64_t id, Closest& h) {
+    const double* p = A.wf_hit + id * kHitDoubles;
+    h.d = p[0]; h.u = p[1]; h.v = p[2];
+    unsigned long long w = (unsigned long long)__double_as_longlong(p[3]);
+    h.object = (int32_t)(uint32_t)w; h.face = (uint32_t)(w >> 32);
 }
 
 // Appends the lanes with pred == true to a queue: one ballot, one atomic per wave.
@@ -52,7 +67,6 @@ DEV uint32_t waveReserve(bool pred, uint32_t* counter) {
 }
 
 constexpr int kWfRegions = 8;   // (light ? 4 : 0) + lobe + 1
-constexpr int kWfQStride = 16;  // counters per depth: [0] trace queue length, [1..8] lobe queue lengths
 
 DEV Rng pathRng(const RenderArgs& A, uint64_t i, bool light, uint64_t& pixel) {
     uint64_t pass;
@@ -150,7 +164,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     }
     storeVertex(P, n, i, nv);
     n++;
-    P.count[i] = n;
+    P.count[i] = ((P.count[i] & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n;
     ray.o = nv.sp.pos;
     ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
     cy.dir = ray.d; cy.fs = fs; cy.p_psa = p_psa;
@@ -265,12 +279,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
             bool light = id >= N;
             uint64_t i = light ? id - N : id;
             const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.count[i];
+            uint32_t n = P.cnt(i);
             if (n > 0) {
                 Ray ray;
                 ray.o = P.ld3(F_POS, n - 1, i);
-                uint64_t n2 = 2 * N;
-                ray.d = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
+                ray.d = loadCarryDir(A, id);
                 hit = closestHit<STATS>(S, ray, st, ty);
                 if (hit.object >= 0) {
                     uint64_t pixel;
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
             int lobe = (r & 3) - 1;
             uint64_t i = light ? sid - N : sid;
             const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.count[i];
+            uint32_t n = P.cnt(i);
             uint64_t pixel;
             Rng rng = pathRng(A, i, light, pixel);
             Carry cy;
@@ -363,7 +376,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A, uint32_t depth
         bool light = id >= N;
         uint64_t i = light ? id - N : id;
         const PathStore& P = light ? A.L : A.E;
-        uint32_t n = P.count[i];
+        uint32_t n = P.cnt(i);
         uint64_t pixel;
         Rng rng = pathRng(A, i, light, pixel);
         Carry cy;

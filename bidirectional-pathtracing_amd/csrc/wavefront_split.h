@@ -65,11 +65,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_trace(RenderArgs A, uint32_t dept
             bool light = id >= N;
             uint64_t i = light ? id - N : id;
             const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.count[i];
+            uint32_t n = P.cnt(i);
             if (n > 0) {
                 Ray ray;
                 ray.o = P.ld3(F_POS, n - 1, i);
-                ray.d = mk3(A.carry[id], A.carry[n2 + id], A.carry[2 * n2 + id]);
+                ray.d = loadCarryDir(A, id);
                 Closest hit = closestHit<STATS>(S, ray, st, ty);
                 if (hit.object >= 0) {
                     uint64_t pixel;
@@ -77,9 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_trace(RenderArgs A, uint32_t dept
                     int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
                     if (!(light && lobe == LOBE_NONE)) {  // a light subpath ends at an absorbing hit (:460, :527)
                         region = (light ? 4 : 0) + lobe + 1;
-                        A.wf_hit_obj[id] = hit.object;
-                        A.wf_hit_face[id] = hit.face;
-                        A.wf_hit_duv[id] = hit.d; A.wf_hit_duv[n2 + id] = hit.u; A.wf_hit_duv[2 * n2 + id] = hit.v;
+                        storeHit(A, id, hit);
                     }
                 }
             }
@@ -139,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t dept
                 int lobe = (int)(r & 3) - 1;
                 uint64_t i = light ? id - N : id;
                 const PathStore& P = light ? A.L : A.E;
-                uint32_t n = P.count[i];
+                uint32_t n = P.cnt(i);
                 uint64_t pixel;
                 Rng rng = pathRng(A, i, light, pixel);
                 Carry cy;
@@ -148,8 +146,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t dept
                 ray.o = P.ld3(F_POS, n - 1, i);
                 ray.d = cy.dir;
                 Closest hit;
-                hit.object = A.wf_hit_obj[id]; hit.face = A.wf_hit_face[id];
-                hit.d = A.wf_hit_duv[id]; hit.u = A.wf_hit_duv[n2 + id]; hit.v = A.wf_hit_duv[2 * n2 + id];
+                loadHit(A, id, hit);
                 cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty)
                              : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty);
                 if (cont) storeCarry(A, id, cy);

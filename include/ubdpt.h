@@ -121,8 +121,10 @@ typedef struct ubdpt_options {
     uint32_t passes_in_flight;  /* passes rendered concurrently by one wavefront batch; 0 -> auto */
     uint32_t accel;             /* 0 = LBVH, 1 = linear scan over all primitives (reference order) */
     uint32_t collect_stats;     /* non-zero: count rays / vertices / traversal steps (slower) */
-    uint32_t pipeline;          /* 0 = default pipeline; others select experimental variants */
-    uint32_t reserved[3];
+    uint32_t pipeline;          /* 0 = default pipeline; 1..3 select variants kept for comparison */
+    uint32_t dense_threshold;   /* pipeline 3: lanes of a wave that must own an (s,t) pair to connect it in place; 0 -> 40 */
+    uint32_t wavefront_depth;   /* bounces run as wavefront launches before the per-lane tail loop; 0 -> default, max 30 */
+    uint32_t streams;           /* batches in flight on separate HIP streams; 0 -> default, max 4 */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */
@@ -206,6 +208,17 @@ int ubdpt_destroy(ubdpt_context* ctx);
  */
 int ubdpt_render_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
                         uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
+
+/*
+ * The same work as ubdpt_render_passes, enqueued without waiting for the GPU: consecutive calls keep
+ * the device busy across call boundaries (the reference's counterpart is UEngine calling
+ * renderPass again as soon as the previous pass returned, uapp/appmanager.cpp:486).
+ * Every entry point that reads results (read_sum*, get_stats, ...) waits for the enqueued passes
+ * first; ubdpt_synchronize waits explicitly and reports errors of the enqueued work.
+ */
+int ubdpt_enqueue_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
+                         uint64_t pass_stride, uint64_t seed, uint32_t* passes_enqueued);
+int ubdpt_synchronize(ubdpt_context* ctx);
 
 /* URenderer::stop (uengine/ubdptrenderer.cpp:83-86): callable from any thread. */
 int ubdpt_request_stop(ubdpt_context* ctx);

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Turns a PMC summary (tools/pmc_summary.py) into profiles/traffic.json: HBM bytes per launch of
+every rendering kernel (the non-counting instantiation, `<false>`).
+
+  bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB. On gfx950 FETCH_SIZE tallies a 128-B fabric read as
+64 B, so a wide coalesced stream reads twice the reported bytes; the factor 2 is applied to every
+kernel here, which makes the figure an upper bound for the kernels whose requests are mostly <= 64 B
+(scattered vertex gathers, tree nodes). The raw counters are kept beside the corrected value.
+"""
+import json
+import sys
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc/summary.json"
+    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/traffic.json"
+    d = json.load(open(src))
+    out, detail = {}, {}
+    for name, c in d.items():
+        if not name.endswith("<false>") or "FETCH_SIZE" not in c:
+            continue
+        n = c["dispatches"]
+        fetch_kib, write_kib = c["FETCH_SIZE"] / n, c.get("WRITE_SIZE", 0.0) / n
+        k = name[: -len("<false>")]
+        out[k] = (2.0 * fetch_kib + write_kib) * 1024.0
+        detail[k] = {"dispatches": n, "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
+                     "uncorrected_bytes_per_launch": (fetch_kib + write_kib) * 1024.0}
+    out["_detail"] = detail
+    out["_formula"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; FETCH doubled for gfx950 (upper bound for <=64-B requests)"
+    json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items()):
+        if not k.startswith("_"):
+            print("%-20s %10.1f MB/launch" % (k, v / 1e6))
+
+
+if __name__ == "__main__":
+    main()
