@@ -29,7 +29,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("bidirectional-pathtracing_amd")
-capi, scenes = pkg.capi, pkg.scenes
+capi, scenes, multigpu = pkg.capi, pkg.scenes, pkg.multigpu
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
@@ -194,11 +194,11 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        first = s * pps * ngpu + rank
-        ctx.enqueue_passes(first, pps, args.seed, pass_stride=ngpu)
+        # step s covers passes [s * pps * ngpu, (s + 1) * pps * ngpu); this rank takes every ngpu-th of them
+        first, count, stride = multigpu.partition_passes(s * pps * ngpu, pps * ngpu, rank, ngpu)
+        ctx.enqueue_passes(first, count, args.seed, pass_stride=stride)
     ctx.read_sum_device(sum_dev.data_ptr())  # waits for the enqueued passes
-    if dist is not None:
-        dist.reduce(sum_dev, dst=0)
+    multigpu.reduce_sum(sum_dev, dist)
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:

@@ -5,6 +5,6 @@ C++ host layer that mirrors the reference's URenderer/UEngine interface. This pa
 that library through ctypes for tests, bench.py and the smoke run, and generates the synthetic
 scenes. It contains no rendering code and no CPU fallback.
 """
-from . import capi, scenes  # noqa: F401
+from . import capi, multigpu, scenes  # noqa: F401
 
-__all__ = ["capi", "scenes"]
+__all__ = ["capi", "multigpu", "scenes"]

@@ -75,3 +75,19 @@ def bsdf_queries(n, seed=7):
     q["wi"] = wi; q["wo"] = wo
     q["u1"] = rng.random(n); q["u2"] = rng.random(n)
     return q
+
+
+# scenes shared by the golden fixtures (tests/golden) and the parity tests
+GOLDEN_SCENES = {
+    "C1": scenes.cornell_c1,
+    "C2": scenes.cornell_c2,
+    "tiny": scenes.tiny_scene,
+    "mesh6k": lambda: scenes.mesh_scene(6000, seed=3, ratio=1.0),
+}
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def load_golden(name):
+    """npz fixture -> dict of arrays (no pickles inside)."""
+    with np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
