@@ -1,0 +1,250 @@
+// hip_renderer.cpp — see hip_renderer.h. Plain C++17, no HIP here: everything device-side goes
+// through the C ABI of include/ubdpt.h.
+#include "hip_renderer.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+
+namespace uhip {
+
+// ---- HipRenderer ------------------------------------------------------------------------------------
+HipRenderer::HipRenderer(int device, const ubdpt_options* options) : m_device(device) {
+    if (options) m_options = *options;
+}
+
+HipRenderer::~HipRenderer() {
+    if (m_ctx) ubdpt_destroy(m_ctx);
+}
+
+bool HipRenderer::initialize(const RenderParameters& render_params, std::shared_ptr<FlatSceneSource> scene) {
+    if (m_ctx) { ubdpt_destroy(m_ctx); m_ctx = nullptr; }
+    if (!scene) { m_status = UBDPT_INVALID_SCENE; return false; }
+    ubdpt_scene_desc desc;
+    std::memset(&desc, 0, sizeof(desc));
+    if (!scene->flatten(desc)) { m_status = UBDPT_INVALID_SCENE; return false; }
+    m_status = ubdpt_create(&desc, &render_params, &m_options, m_device, &m_ctx);
+    return m_status == UBDPT_SUCCESS;
+}
+
+bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t /*num_threads*/,
+                             std::function<void(double)>& update_progress_callback) {
+    if (!m_ctx || !pixel_buffer) { m_status = UBDPT_UNINITIALIZED; return false; }
+    // the device sum holds this pass only; it is then added to the caller's running sum
+    if ((m_status = ubdpt_upload_sum(m_ctx, nullptr)) != UBDPT_SUCCESS) return false;
+    uint32_t done = 0;
+    m_status = ubdpt_render_passes(m_ctx, curr_pass, 1, 1, m_seed, &done);
+    if (m_status != UBDPT_SUCCESS || done != 1) return false;   // stopped: the engine drops the write buffer
+    if ((m_status = ubdpt_read_sum(m_ctx, pixel_buffer->ptr(), 1)) != UBDPT_SUCCESS) return false;
+    if (update_progress_callback != nullptr) {
+        std::lock_guard<std::mutex> lock(m_progress_mutex);
+        update_progress_callback(1.0);
+    }
+    return true;
+}
+
+void HipRenderer::stop() {
+    if (m_ctx) ubdpt_request_stop(m_ctx);
+}
+
+bool HipRenderer::renderPassesOnDevice(size_t first_pass, size_t n, size_t* done_out) {
+    if (done_out) *done_out = 0;
+    if (!m_ctx) { m_status = UBDPT_UNINITIALIZED; return false; }
+    size_t done_total = 0;
+    while (done_total < n) {
+        uint32_t chunk = (uint32_t)std::min<size_t>(n - done_total, 1u << 20), done = 0;
+        m_status = ubdpt_render_passes(m_ctx, first_pass + done_total, chunk, 1, m_seed, &done);
+        done_total += done;
+        if (m_status != UBDPT_SUCCESS) break;
+    }
+    if (done_out) *done_out = done_total;
+    return m_status == UBDPT_SUCCESS;
+}
+
+bool HipRenderer::uploadSum(const SumBuffer* sum) {
+    if (!m_ctx) { m_status = UBDPT_UNINITIALIZED; return false; }
+    m_status = ubdpt_upload_sum(m_ctx, sum ? sum->ptr() : nullptr);
+    return m_status == UBDPT_SUCCESS;
+}
+
+bool HipRenderer::readSum(SumBuffer& out, bool add_into) {
+    if (!m_ctx) { m_status = UBDPT_UNINITIALIZED; return false; }
+    m_status = ubdpt_read_sum(m_ctx, out.ptr(), add_into ? 1 : 0);
+    return m_status == UBDPT_SUCCESS;
+}
+
+// ---- .ur files -----------------------------------------------------------------------------------------
+Result writeUr(const std::string& filename, uint64_t curr_pass, const RenderParameters& params, RendererType type,
+               const double* sums) {
+    std::ofstream out(filename, std::ios::binary);
+    if (!out.is_open()) return Result::UError;
+    int32_t t = (int32_t)type;
+    out.write(reinterpret_cast<const char*>(&curr_pass), sizeof(curr_pass));
+    out.write(reinterpret_cast<const char*>(&params), sizeof(params));
+    out.write(reinterpret_cast<const char*>(&t), sizeof(t));
+    out.write(reinterpret_cast<const char*>(sums), sizeof(double) * 3 * params.img_res_x * params.img_res_y);
+    return out.good() ? Result::USuccess : Result::UError;
+}
+
+Result readUr(const std::string& filename, uint64_t& curr_pass, RenderParameters& params, RendererType& type,
+              std::vector<double>& sums) {
+    std::ifstream in(filename, std::ios::binary);
+    if (!in.is_open()) return Result::UError;
+    int32_t t = 0;
+    in.read(reinterpret_cast<char*>(&curr_pass), sizeof(curr_pass));
+    in.read(reinterpret_cast<char*>(&params), sizeof(params));
+    in.read(reinterpret_cast<char*>(&t), sizeof(t));
+    if (!in.good()) return Result::UInvalidFormat;
+    // the reference trusts the header; a size that cannot be allocated or read is reported instead
+    if (params.img_res_x == 0 || params.img_res_y == 0 || params.img_res_x > 65536 || params.img_res_y > 65536)
+        return Result::UInvalidFormat;
+    type = (RendererType)t;
+    sums.assign((size_t)3 * params.img_res_x * params.img_res_y, 0.0);
+    in.read(reinterpret_cast<char*>(sums.data()), sizeof(double) * sums.size());
+    if ((size_t)in.gcount() != sizeof(double) * sums.size()) return Result::UInvalidFormat;
+    return Result::USuccess;
+}
+
+// ---- HipEngine -------------------------------------------------------------------------------------------
+HipEngine::HipEngine(int device, const ubdpt_options* options) : m_device(device) {
+    if (options) m_options = *options;
+}
+
+bool HipEngine::initPixelBuffers(size_t w, size_t h) {
+    m_buffers[0] = std::make_shared<SumBuffer>(w, h);
+    m_buffers[1] = std::make_shared<SumBuffer>(w, h);
+    return m_buffers[0] && m_buffers[1];
+}
+
+Result HipEngine::newRendering(const RenderParameters& params, RendererType type) {
+    if (!m_scene) return Result::UInvalidScene;
+    m_curr_pass = 0;
+    m_params = params;
+    m_write = 0; m_read = 1;
+    if (!initPixelBuffers(params.img_res_x, params.img_res_y)) return Result::UError;
+    // both enumerators are rendered by the HIP renderer here; the value is kept for the .ur header
+    if (type != RendererType::BDPT && type != RendererType::BDPT_HIP) return Result::UInvalidFormat;
+    m_renderer = std::make_unique<HipRenderer>(m_device, &m_options);
+    m_type = type;
+    if (!m_renderer->initialize(params, m_scene)) return Result::UError;
+    return Result::USuccess;
+}
+
+Result HipEngine::saveRendering(const std::string& filename) const {
+    if (!m_buffers[m_read]) return Result::UError;
+    return writeUr(filename, m_curr_pass, m_params, m_type, m_buffers[m_read]->ptr());
+}
+
+Result HipEngine::loadRendering(const std::string& filename, RenderParameters& params, RendererType& type, size_t& curr_pass) {
+    if (!m_scene) return Result::UInvalidScene;
+    uint64_t pass = 0;
+    RenderParameters p{};
+    RendererType t{};
+    std::vector<double> sums;
+    Result r = readUr(filename, pass, p, t, sums);
+    if (r != Result::USuccess) return r;
+    if (t != RendererType::BDPT && t != RendererType::BDPT_HIP) return Result::UInvalidFormat;
+    m_write = 0; m_read = 1;
+    m_curr_pass = pass; m_params = p; m_type = t;
+    if (!initPixelBuffers(p.img_res_x, p.img_res_y)) return Result::UError;
+    std::memcpy(m_buffers[m_read]->ptr(), sums.data(), sizeof(double) * sums.size());
+    m_renderer = std::make_unique<HipRenderer>(m_device, &m_options);
+    if (!m_renderer->initialize(m_params, m_scene)) return Result::UError;
+    params = m_params; curr_pass = m_curr_pass; type = m_type;
+    return Result::USuccess;
+}
+
+Result HipEngine::renderPass(size_t num_threads, std::function<void(double)> update_progress_callback) {
+    if (!m_renderer) return Result::UUninitialized;
+    if (m_curr_pass != 0) m_buffers[m_write]->setFrom(*m_buffers[m_read]);
+    if (num_threads <= 0) num_threads = 1;
+    else if (num_threads > kMaxThreads) num_threads = kMaxThreads;
+    bool complete = m_renderer->renderPass(m_buffers[m_write], m_curr_pass, num_threads, update_progress_callback);
+    if (complete) {
+        m_curr_pass++;
+        std::swap(m_read, m_write);
+        return Result::USuccess;
+    }
+    return m_renderer->lastStatus() == UBDPT_STOPPED || m_renderer->lastStatus() == UBDPT_SUCCESS ? Result::UStopped
+                                                                                                     : Result::UError;
+}
+
+Result HipEngine::renderPasses(size_t n) {
+    if (!m_renderer) return Result::UUninitialized;
+    if (n == 0) return Result::USuccess;
+    // device sum := everything rendered so far, then n more passes on top, one read-back at the end
+    if (!m_renderer->uploadSum(m_curr_pass != 0 ? m_buffers[m_read].get() : nullptr)) return Result::UError;
+    size_t done = 0;
+    bool ok = m_renderer->renderPassesOnDevice(m_curr_pass, n, &done);
+    if (!ok && m_renderer->lastStatus() != UBDPT_STOPPED) return Result::UError;
+    if (done > 0) {
+        if (!m_renderer->readSum(*m_buffers[m_write], false)) return Result::UError;
+        m_curr_pass += done;
+        std::swap(m_read, m_write);
+    }
+    return ok ? Result::USuccess : Result::UStopped;
+}
+
+void HipEngine::stop() {
+    if (m_renderer) m_renderer->stop();
+}
+
+}  // namespace uhip
+
+// ---- C shim over the classes (used by the Python tests; a C++ caller uses the classes directly) ---------
+extern "C" {
+
+struct uhip_engine {
+    uhip::HipEngine engine;
+    uhip_engine(int device, const ubdpt_options* o) : engine(device, o) {}
+};
+
+uhip_engine* uhip_engine_create(int device, const ubdpt_options* options) { return new uhip_engine(device, options); }
+void uhip_engine_destroy(uhip_engine* e) { delete e; }
+void uhip_engine_set_scene(uhip_engine* e, const ubdpt_scene_desc* desc) {
+    e->engine.setScene(std::make_shared<uhip::BorrowedScene>(*desc));
+}
+int uhip_engine_new_rendering(uhip_engine* e, const ubdpt_render_params* p, int type) {
+    return (int)e->engine.newRendering(*p, (uhip::RendererType)type);
+}
+int uhip_engine_render_pass(uhip_engine* e, size_t num_threads, void (*progress)(double)) {
+    std::function<void(double)> cb;
+    if (progress) cb = progress;
+    return (int)e->engine.renderPass(num_threads, cb);
+}
+int uhip_engine_render_passes(uhip_engine* e, size_t n) { return (int)e->engine.renderPasses(n); }
+void uhip_engine_stop(uhip_engine* e) { e->engine.stop(); }
+size_t uhip_engine_curr_pass(uhip_engine* e) { return e->engine.currPass(); }
+int uhip_engine_sum(uhip_engine* e, double* out) {
+    const uhip::SumBuffer* s = e->engine.sum();
+    if (!s || !out) return (int)uhip::Result::UNoData;
+    std::memcpy(out, s->ptr(), sizeof(double) * 3 * s->width() * s->height());
+    return (int)uhip::Result::USuccess;
+}
+int uhip_engine_save(uhip_engine* e, const char* filename) { return (int)e->engine.saveRendering(filename); }
+int uhip_engine_load(uhip_engine* e, const char* filename, ubdpt_render_params* params, int* type, size_t* curr_pass) {
+    uhip::RendererType t{};
+    int r = (int)e->engine.loadRendering(filename, *params, t, *curr_pass);
+    *type = (int)t;
+    return r;
+}
+int uhip_ur_write(const char* filename, uint64_t curr_pass, const ubdpt_render_params* params, int type, const double* sums) {
+    return (int)uhip::writeUr(filename, curr_pass, *params, (uhip::RendererType)type, sums);
+}
+// sums may be NULL to read the header only; otherwise it must hold 3 * W * H doubles
+int uhip_ur_read(const char* filename, uint64_t* curr_pass, ubdpt_render_params* params, int* type, double* sums,
+                 size_t sums_capacity) {
+    std::vector<double> v;
+    uhip::RendererType t{};
+    int r = (int)uhip::readUr(filename, *curr_pass, *params, t, v);
+    if (r != 0) return r;
+    *type = (int)t;
+    if (sums) {
+        if (sums_capacity < v.size()) return (int)uhip::Result::UError;
+        std::memcpy(sums, v.data(), sizeof(double) * v.size());
+    }
+    return r;
+}
+
+}  // extern "C"

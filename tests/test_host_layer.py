@@ -1,0 +1,141 @@
+"""The C++ host layer (HipEngine / HipRenderer, mirrors of UEngine / URenderer) through its C shim.
+
+CPU part: the library loads, exports its symbols, and the .ur checkpoint format is byte-compatible
+with uengine/uengine.cpp:65-142 (raw size_t pass counter, raw 56-byte URenderParameters, raw 4-byte
+URendererType, W*H raw dvec3 sums). GPU part: engine semantics against the C ABI."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+from util import capi, pkg, scenes
+
+import importlib
+
+hostapi = importlib.import_module("bidirectional-pathtracing_amd.hostapi")
+
+SEED = 0x5EED
+
+
+def test_host_library_exports():
+    lib = C.CDLL(hostapi.LIB_PATH)
+    for n in hostapi.EXPORTS:
+        assert hasattr(lib, n), n
+
+
+def test_ur_file_layout_is_the_reference_layout(tmp_path):
+    p = scenes.make_params(5, 3, pixel_subdiv=2, lens_subdiv=3, min_depth=7, focus=1.25, lens=0.002)
+    sums = np.arange(5 * 3 * 3, dtype=np.float64).reshape(3, 5, 3) * 0.5
+    path = str(tmp_path / "a.ur")
+    assert hostapi.ur_write(path, 42, p, hostapi.BDPT_HIP, sums) == hostapi.USUCCESS
+    raw = open(path, "rb").read()
+    assert len(raw) == hostapi.UR_HEADER_BYTES + 5 * 3 * 24
+    head = struct.unpack("<Q5Q2di", raw[:68])
+    assert head == (42, 5, 3, 2, 3, 7, 1.25, 0.002, hostapi.BDPT_HIP)
+    assert np.array_equal(np.frombuffer(raw[68:], np.float64), sums.reshape(-1))   # [y][x][rgb], row-major
+    st, cp, p2, t, s2 = hostapi.ur_read(path)
+    assert st == hostapi.USUCCESS and cp == 42 and t == hostapi.BDPT_HIP
+    assert (p2.img_res_x, p2.img_res_y, p2.min_depth, p2.lens_size) == (5, 3, 7, 0.002)
+    assert np.array_equal(s2, sums)
+
+
+def test_ur_read_errors(tmp_path):
+    assert hostapi.ur_read(str(tmp_path / "missing.ur"))[0] == hostapi.UERROR        # cannot open (uengine.cpp:98-101)
+    short = tmp_path / "short.ur"
+    short.write_bytes(b"\x00" * 10)
+    assert hostapi.ur_read(str(short))[0] == hostapi.UINVALID_FORMAT
+    p = scenes.make_params(4, 4)
+    full = tmp_path / "full.ur"
+    assert hostapi.ur_write(str(full), 1, p, hostapi.BDPT, np.zeros((4, 4, 3))) == hostapi.USUCCESS
+    trunc = tmp_path / "trunc.ur"
+    trunc.write_bytes(full.read_bytes()[:-8])
+    assert hostapi.ur_read(str(trunc))[0] == hostapi.UINVALID_FORMAT
+
+
+# ---- GPU ---------------------------------------------------------------------------------------------------
+def c2(w=48, h=48):
+    sc, params, _ = scenes.make_config("C2")
+    params.img_res_x, params.img_res_y = w, h
+    return sc, params
+
+
+@pytest.mark.gpu
+def test_engine_pass_by_pass_equals_batched_and_abi():
+    sc, params = c2()
+    with hostapi.Engine(sc) as eng:
+        assert eng.render_pass() == hostapi.UUNINITIALIZED               # no rendering yet (uengine.cpp:147-150)
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        calls = []
+        for k in range(3):
+            assert eng.render_pass(8, calls.append) == hostapi.USUCCESS
+            assert eng.curr_pass == k + 1
+        assert calls and calls[-1] == 1.0
+        a = eng.sum()
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        assert eng.render_passes(3) == hostapi.USUCCESS and eng.curr_pass == 3
+        b = eng.sum()
+    with capi.Context(sc, params) as ctx:
+        ctx.render_passes(0, 3, SEED)
+        c = ctx.read_sum()
+    # same samples; the per-pass path adds pass sums on the host, the batched one accumulates on the device
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-13) and np.allclose(b, c, rtol=1e-12, atol=1e-13)
+    assert a.sum() > 0
+
+
+@pytest.mark.gpu
+def test_engine_save_load_resume(tmp_path):
+    sc, params = c2(32, 32)
+    path = str(tmp_path / "r.ur")
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        assert eng.render_passes(2) == hostapi.USUCCESS
+        assert eng.save(path) == hostapi.USUCCESS
+        assert eng.render_passes(3) == hostapi.USUCCESS
+        straight = eng.sum()
+    with hostapi.Engine(sc) as eng:
+        st, p, t, cp = eng.load(path)
+        assert st == hostapi.USUCCESS and cp == 2 and t == hostapi.BDPT_HIP and p.img_res_x == 32
+        assert eng.curr_pass == 2
+        assert eng.render_pass() == hostapi.USUCCESS                    # resume pass by pass ...
+        assert eng.render_passes(2) == hostapi.USUCCESS                 # ... and batched
+        resumed = eng.sum()
+    assert np.allclose(straight, resumed, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_engine_rejects_missing_scene_and_unknown_renderer(tmp_path):
+    sc, params = c2(16, 16)
+    lib = hostapi.load_library()
+    h = lib.uhip_engine_create(0, None)
+    assert lib.uhip_engine_new_rendering(h, C.byref(params), hostapi.BDPT_HIP) == hostapi.UINVALID_SCENE   # uengine.cpp:35-38
+    lib.uhip_engine_destroy(h)
+    path = str(tmp_path / "x.ur")
+    assert hostapi.ur_write(path, 1, params, 7, np.zeros((16, 16, 3))) == hostapi.USUCCESS
+    with hostapi.Engine(sc) as eng:
+        assert eng.load(path)[0] == hostapi.UINVALID_FORMAT                                                 # uengine.cpp:128-129
+
+
+@pytest.mark.gpu
+def test_engine_stop_discards_the_pass():
+    import threading
+    sc, params = c2(256, 256)
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        assert eng.render_passes(1) == hostapi.USUCCESS
+        before = eng.sum()
+        # a stop that arrives while many passes are queued ends the batch early with UStopped;
+        # finished passes stay, the counter says how many
+        t = threading.Timer(0.02, eng.stop)
+        t.start()
+        st = eng.render_passes(4096)
+        t.join()
+        assert st in (hostapi.USTOPPED, hostapi.USUCCESS)
+        if st == hostapi.USTOPPED:
+            assert 1 <= eng.curr_pass < 4097
+        after = eng.sum()
+        assert np.all(after >= before - 1e-12)
+        # the flag is reset by the next call, as UBDPTRenderer::renderPass does (ubdptrenderer.cpp:37)
+        n = eng.curr_pass
+        assert eng.render_pass() == hostapi.USUCCESS and eng.curr_pass == n + 1
