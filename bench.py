@@ -237,6 +237,9 @@ def main():
                        "wavefront_depth": args.wavefront_depth or "default", "partition": f"passes round-robin over {ngpu} GPU(s)"},
             "mrays_per_s": value * work["rays_per_pixel_sample"],
             "rays_per_pixel_sample": work["rays_per_pixel_sample"],
+            "work_per_pixel_sample": {k: work[k] for k in ("closest_per_pixel_sample", "shadow_per_pixel_sample",
+                                                           "nodes_per_ray", "prims_per_ray", "eye_vertices",
+                                                           "light_vertices", "splats")},
             "mean_radiance": [float(x) for x in (img.reshape(-1, 3).mean(0) / total_passes)],
             "finite": bool(np.isfinite(img).all()),
             "kernels": {k: {"ms_per_launch": v["ms"] / max(1, v["launches"]), "launches": v["launches"],
