@@ -260,3 +260,27 @@ def test_stop_request_is_honoured(oracle_mod):
     st, done2 = ctx.render_passes(done, 1, SEED)
     assert st == capi.SUCCESS and done2 == 1
     ctx.close()
+
+
+@pytest.mark.parametrize("n_tris,n_rays", [(100_000, 1 << 14), (2_000_000, 1 << 11)])
+def test_large_mesh_lbvh_equals_linear_scan(n_tris, n_rays):
+    """At the sizes of the mesh configurations the CPU oracle's O(#triangles) scan is too slow for a test,
+    so the LBVH is checked against the device's own linear scan, which runs the same fp64 leaf tests in
+    the reference's order (and is itself checked against the oracle on the small scenes above)."""
+    scene = scenes.mesh_scene(n_tris, seed=1, ratio=1.0)
+    params = scenes.make_params(64, 64)
+    rays, segs = ray_batch(n_rays, seed=42), segment_batch(n_rays, seed=43)
+    res = []
+    for accel in (0, 1):
+        opt = capi.Options()
+        opt.accel = accel
+        with capi.Context(scene, params, opt) as ctx:
+            res.append((ctx.intersect_batch(rays), ctx.visibility_batch(segs)))
+    (h0, v0), (h1, v1) = res
+    assert np.array_equal(h0["hit"], h1["hit"]) and np.array_equal(h0["object"], h1["object"])
+    assert np.array_equal(h0["face"], h1["face"])
+    m = h1["hit"] == 1
+    assert m.sum() > n_rays // 2
+    for f in ("d", "pos", "Ng", "Ns", "Ts", "Bs", "tex_u", "tex_v"):
+        assert np.array_equal(h0[f][m].view(np.uint64), h1[f][m].view(np.uint64)), f
+    assert np.array_equal(v0, v1) and 0 < v1.sum() < n_rays
