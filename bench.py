@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,9 +153,13 @@ def main():
     if ngpu > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = local_rank if ngpu > 1 else 0
+        dev = 0 if args.single_device else local_rank
+        torch.cuda.set_device(dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group(args.dist_backend)
+    device = (0 if args.single_device else local_rank) if ngpu > 1 else 0
     torch.cuda.set_device(device)
 
     scene, params, cfg_spp = scenes.make_config(args.config)
@@ -187,7 +193,7 @@ def main():
         ctx.render_passes(base + (w * pps * ngpu) + rank, pps, args.seed, pass_stride=ngpu)
     if dist is not None and args.warmup:
         ctx.read_sum_device(sum_dev.data_ptr())
-        dist.reduce(sum_dev, dst=0)
+        multigpu.reduce_sum(sum_dev, dist)
     ctx.upload_sum(None)
     ctx.reset_stats()
 
@@ -202,7 +208,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{device}" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 

@@ -26,5 +26,10 @@ def reduce_sum(sum_tensor, dist=None, dst=0):
     """Adds every rank's sum buffer into rank `dst`'s (in place). `dist` = torch.distributed or None
     for a single process."""
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(sum_tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if sum_tensor.is_cuda and dist.get_backend() == "gloo":  # CPU rehearsal of the GPU path: reduce through the host
+            host = sum_tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            sum_tensor.copy_(host)
+        else:
+            dist.reduce(sum_tensor, dst=dst, op=dist.ReduceOp.SUM)
     return sum_tensor
