@@ -33,15 +33,18 @@ struct DTexture {
     uint64_t texel_offset;  // byte offset into the RGBA8888 texel pool
 };
 
-// 64-byte BVH node: the boxes of both children (fp32, rounded outward and padded) and their links.
+// 128-byte four-wide BVH node (two 64-byte lines, fetched together): the boxes of up to four children
+// (fp32, rounded outward and padded) and their links. Traversal is a chain of dependent node
+// fetches, so halving the depth of the tree (the binary LBVH is collapsed two levels at a time)
+// halves the number of memory round trips per ray.
 // child >= 0: internal node index; child < 0: leaf holding primitive ~child; kEmptyChild: nothing.
 struct __attribute__((aligned(16))) BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t child0, child1;
-    int32_t pad0, pad1;
+    float lo[4][3];
+    float hi[4][3];
+    int32_t child[4];
+    int32_t pad[4];
 };
-static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+static_assert(sizeof(BvhNode) == 128, "BvhNode must be 128 bytes");
 constexpr int32_t kEmptyChild = 0x7fffffff;
 
 // 48-byte primitive in tree (Morton) order: object-LOCAL float positions exactly as the mesh holds

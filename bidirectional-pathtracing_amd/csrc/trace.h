@@ -193,21 +193,29 @@ constexpr int32_t kTraversalDone = kEmptyChild;
 
 // One traversal step from an internal node: tests both children, returns the next node to visit
 // (near child first, far child pushed) or pops / finishes when neither child is hit.
-DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool ordered,
+DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
+    if (tb < ta) { float t = ta; ta = tb; tb = t; int32_t c = ca; ca = cb; cb = c; }
+}
+DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
                     TraceCounters* tc) {
     const BvhNode nd = S.nodes[node];
     if (tc) tc->nodes++;
-    float tn0, tn1;
-    bool h0 = nd.child0 != kEmptyChild && slabF(nd.lo0, nd.hi0, q, tmax, tn0);
-    bool h1 = nd.child1 != kEmptyChild && slabF(nd.lo1, nd.hi1, q, tmax, tn1);
-    int32_t c0 = nd.child0, c1 = nd.child1;
-    if (h0 && h1) {
-        if (ordered && tn1 < tn0) { int32_t t = c0; c0 = c1; c1 = t; }
-        st.push(c1);
-        return c0;
-    }
-    if (h0) return c0;
-    if (h1) return c1;
+    const float inf = __builtin_inff();
+    float t0, t1, t2, t3;
+    int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
+    if (!(c0 != kEmptyChild && slabF(nd.lo[0], nd.hi[0], q, tmax, t0))) t0 = inf;
+    if (!(c1 != kEmptyChild && slabF(nd.lo[1], nd.hi[1], q, tmax, t1))) t1 = inf;
+    if (!(c2 != kEmptyChild && slabF(nd.lo[2], nd.hi[2], q, tmax, t2))) t2 = inf;
+    if (!(c3 != kEmptyChild && slabF(nd.lo[3], nd.hi[3], q, tmax, t3))) t3 = inf;
+    // entry distances are finite for a hit (the ray parameter interval is clipped to [.., tmax]); sort near
+    // to far with a five-comparator network, misses (inf) end up last
+    sortPair(t0, c0, t1, c1); sortPair(t2, c2, t3, c3);
+    sortPair(t0, c0, t2, c2); sortPair(t1, c1, t3, c3);
+    sortPair(t1, c1, t2, c2);
+    if (t3 < inf) st.push(c3);
+    if (t2 < inf) st.push(c2);
+    if (t1 < inf) st.push(c1);
+    if (t0 < inf) return c0;
     return st.sp ? st.pop() : kTraversalDone;
 }
 

@@ -18,6 +18,11 @@ namespace ub {
 
 constexpr uint32_t kQueueSentinel = 0xffffffffu;
 
+// waves per SIMD the ray-tracing kernels are compiled for (register budget = 512 / this)
+#ifndef UBDPT_TRACE_WAVES
+#define UBDPT_TRACE_WAVES 1
+#endif
+
 // Appends the lanes with pred to a queue with ONE global atomic per workgroup. Every lane of the
 // workgroup must call it. Returns the lane's slot (valid when pred).
 DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_t* s_base) {
@@ -40,7 +45,7 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 
 // ---- trace ------------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_wf_trace(RenderArgs A, uint32_t depth) {
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
     __shared__ uint32_t s_base;
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t dept
 
 // ---- connections: visibility, then evaluation -----------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_pair_visible(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Traversal statistics per kernel (counting build): nodes and primitive tests per ray.
+  python tools/traversal_stats.py C3 [passes]"""
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("bidirectional-pathtracing_amd")
+capi, scenes = pkg.capi, pkg.scenes
+name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+scene, params, _ = scenes.make_config(name)
+opt = capi.Options()
+opt.collect_stats = 1
+with capi.Context(scene, params, opt) as ctx:
+    ctx.render_passes(0, passes, 0x5EED)
+    s = ctx.stats()
+ps = s["pixel_samples"]
+print(name, "pixel-samples", ps, "closest/ps %.2f shadow/ps %.2f eye %.2f light %.2f conn/ps %.2f" % (
+    s["closest_hit_rays"] / ps, s["shadow_rays"] / ps, s["eye_vertices"] / ps, s["light_vertices"] / ps, s["connections"] / ps))
+for k in s["kernels"]:
+    rays = k["closest_hit_rays"] + k["shadow_rays"]
+    if rays:
+        print("%-16s rays %10d nodes/ray %6.2f prims/ray %5.2f ms/launch %.3f" % (
+            k["name"], rays, k["nodes_visited"] / rays, k["prims_tested"] / rays, k["ms"] / max(1, k["launches"])))
