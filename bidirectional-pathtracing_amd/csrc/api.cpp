@@ -807,6 +807,7 @@ int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
         ks.launches = c->kernel_launches[k]; ks.ms = c->kernel_ms[k]; ks.units = c->kernel_units[k];
         const unsigned long long* h = c->kernel_counters[k];
         ks.closest_hit_rays = h[0]; ks.shadow_rays = h[1]; ks.nodes_visited = h[6]; ks.prims_tested = h[7];
+        ks.wave_node_steps = h[11]; ks.wave_prim_steps = h[12];
         ks.vertices = h[2] + h[3]; ks.fb_updates = h[10];
     }
     return UBDPT_SUCCESS;

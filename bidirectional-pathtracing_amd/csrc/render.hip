@@ -14,11 +14,13 @@ namespace ub {
 constexpr int kBlock = 256;
 
 // counters, indices into RenderArgs::counters
-enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB, C_NUM };
+enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB,
+       C_WAVE_NODES, C_WAVE_PRIMS, C_NUM };
+static_assert(C_NUM <= kNumCounters, "counter block too small");
 
 struct Tally {
     uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0, fb = 0;
-    TraceCounters tc{0, 0};
+    TraceCounters tc{0, 0, 0, 0};
 };
 
 DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid) {
@@ -52,6 +54,8 @@ DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_
     atomicAdd(&counters[C_SPLAT], (unsigned long long)ty.splat);
     atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
     atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    if (ty.tc.wave_nodes) atomicAdd(&counters[C_WAVE_NODES], (unsigned long long)ty.tc.wave_nodes);
+    if (ty.tc.wave_prims) atomicAdd(&counters[C_WAVE_PRIMS], (unsigned long long)ty.tc.wave_prims);
     atomicAdd(&counters[C_CAPPED], (unsigned long long)ty.capped);
     atomicAdd(&counters[C_FB], (unsigned long long)ty.fb);
     atomicAdd(&counters[C_EYE_V], (unsigned long long)eye_v);

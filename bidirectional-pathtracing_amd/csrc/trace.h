@@ -72,8 +72,15 @@ struct Closest {
 };
 
 struct TraceCounters {
-    uint32_t nodes, prims;
+    uint32_t nodes, prims;            // per lane: node visits, primitive tests
+    uint32_t wave_nodes, wave_prims;  // per wave: times the wave executed a node step / a primitive test
 };
+// Counts one wave-level execution of the code it stands in: nodes / (64 * wave_nodes) is the SIMD
+// utilisation of the node step, prims / (64 * wave_prims) that of the primitive test.
+DEV void countWaveStep(uint32_t& c) {
+    unsigned long long m = __ballot(1);
+    if ((threadIdx.x & 63) == (uint32_t)(__ffsll((long long)m) - 1)) c++;
+}
 
 // Per-ray cache of the object-local ray and of the bounding-sphere gate result.
 struct LocalCache {
@@ -199,7 +206,7 @@ DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
 DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
                     TraceCounters* tc) {
     const BvhNode nd = S.nodes[node];
-    if (tc) tc->nodes++;
+    if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
     const float inf = __builtin_inff();
     float t0, t1, t2, t3;
     int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
@@ -235,7 +242,7 @@ DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack st, TraceCounters
     for (;;) {
         while (node >= 0 && node != kTraversalDone) node = descend(S, node, q, tmax, st, true, tc);
         if (node == kTraversalDone) break;
-        if (tc) tc->prims++;
+        if (tc) { tc->prims++; countWaveStep(tc->wave_prims); }
         testPrimClosest(S, r, S.prims[~node], c, best);
         tmax = floatUp(best.d);
         node = st.sp ? st.pop() : kTraversalDone;
@@ -259,7 +266,7 @@ DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters* tc) 
     for (;;) {
         while (node >= 0 && node != kTraversalDone) node = descend(S, node, q, tmax, st, false, tc);
         if (node == kTraversalDone) break;
-        if (tc) tc->prims++;
+        if (tc) { tc->prims++; countWaveStep(tc->wave_prims); }
         if (testPrimBlocks(S, r, S.prims[~node], c, dist)) return false;
         node = st.sp ? st.pop() : kTraversalDone;
     }

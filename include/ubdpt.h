@@ -157,6 +157,9 @@ typedef struct ubdpt_kernel_stat {
     double   units;     /* work items summed over launches (rays, vertices, pixel-samples ...) */
     /* work counted inside this kernel (only with collect_stats; zero otherwise) */
     uint64_t closest_hit_rays, shadow_rays, nodes_visited, prims_tested, vertices, fb_updates;
+    /* wave-level executions of the node step / the primitive test: nodes_visited / (64 * wave_node_steps)
+     * is the SIMD utilisation of the traversal */
+    uint64_t wave_node_steps, wave_prim_steps;
 } ubdpt_kernel_stat;
 
 typedef struct ubdpt_stats {

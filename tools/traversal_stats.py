@@ -25,3 +25,7 @@ for k in s["kernels"]:
     if rays:
         print("%-16s rays %10d nodes/ray %6.2f prims/ray %5.2f ms/launch %.3f" % (
             k["name"], rays, k["nodes_visited"] / rays, k["prims_tested"] / rays, k["ms"] / max(1, k["launches"])))
+for k in s["kernels"]:
+    if k["wave_node_steps"]:
+        print("%-16s SIMD utilisation: node step %.1f / 64 lanes, primitive test %.1f / 64 lanes" % (
+            k["name"], k["nodes_visited"] / k["wave_node_steps"], k["prims_tested"] / max(1, k["wave_prim_steps"])))
