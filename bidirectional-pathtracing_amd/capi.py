@@ -98,7 +98,8 @@ class Stats(C.Structure):
 # Every entry point include/ubdpt.h declares; tests check that the library exports all of them.
 EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
-    "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum", "ubdpt_read_sum_device", "ubdpt_upload_sum",
+    "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
+    "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb",
     "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
@@ -159,6 +160,7 @@ def load_library(path=None):
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
     lib.ubdpt_upload_sum.argtypes = [vp, vp]
+    lib.ubdpt_image_rgb.argtypes = [vp, C.c_uint64, C.c_double, vp]
     lib.ubdpt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ubdpt_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ubdpt_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
@@ -256,6 +258,13 @@ class Context:
         rgb = np.ascontiguousarray(rgb, np.float64)
         assert rgb.shape == (self.height, self.width, 3)
         _check(self.lib.ubdpt_upload_sum(self.handle, rgb.ctypes.data), "ubdpt_upload_sum")
+
+    def image_rgb(self, passes, gamma=2.2):
+        """UEngine::imageRGB of the device sum; None when there is no data (passes == 0 or gamma <= 0)."""
+        out = np.zeros((self.height, self.width, 3), np.float64)
+        st = self.lib.ubdpt_image_rgb(self.handle, passes, gamma, out.ctypes.data)
+        _check(st, "ubdpt_image_rgb", allow=(NO_DATA,))
+        return out if st == SUCCESS else None
 
     def intersect_batch(self, rays):
         rays = np.ascontiguousarray(rays, RAY_DTYPE)

@@ -670,6 +670,48 @@ int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
     return UBDPT_SUCCESS;
 }
 
+// uengine/uconverter.cpp:3-76: the fit functions and their sums over the three wavelength bins
+static RgbFit makeRgbFit() {
+    auto xFit = [](double wave) {
+        double t1 = (wave - 442.0) * ((wave < 442.0) ? 0.0624 : 0.0374);
+        double t2 = (wave - 599.8) * ((wave < 599.8) ? 0.0264 : 0.0323);
+        double t3 = (wave - 501.1) * ((wave < 501.1) ? 0.0490 : 0.0382);
+        return 0.362 * std::exp(-0.5 * t1 * t1) + 1.056 * std::exp(-0.5 * t2 * t2) - 0.065 * std::exp(-0.5 * t3 * t3);
+    };
+    auto yFit = [](double wave) {
+        double t1 = (wave - 568.8) * ((wave < 568.8) ? 0.0213 : 0.0247);
+        double t2 = (wave - 530.9) * ((wave < 530.9) ? 0.0613 : 0.0322);
+        return 0.821 * std::exp(-0.5 * t1 * t1) + 0.286 * std::exp(-0.5 * t2 * t2);
+    };
+    auto zFit = [](double wave) {
+        double t1 = (wave - 437.0) * ((wave < 437.0) ? 0.0845 : 0.0278);
+        double t2 = (wave - 459.0) * ((wave < 459.0) ? 0.0385 : 0.0725);
+        return 1.217 * std::exp(-0.5 * t1 * t1) + 0.681 * std::exp(-0.5 * t2 * t2);
+    };
+    RgbFit f;
+    f.sumX = f.sumY = f.sumZ = mk3(0, 0, 0);
+    for (size_t l = 0; l < 123; l++) {
+        f.sumX.x += xFit(626 + l); f.sumX.y += xFit(503 + l); f.sumX.z += xFit(380 + l);
+        f.sumY.x += yFit(626 + l); f.sumY.y += yFit(503 + l); f.sumY.z += yFit(380 + l);
+        f.sumZ.x += zFit(626 + l); f.sumZ.y += zFit(503 + l); f.sumZ.z += zFit(380 + l);
+    }
+    return f;
+}
+
+int ubdpt_image_rgb(ubdpt_context* c, uint64_t passes, double gamma, double* rgb) {
+    if (!c || !rgb) return UBDPT_INVALID_ARG;
+    if (passes == 0 || !(gamma > 0)) return UBDPT_NO_DATA;  // uengine/uengine.cpp:184-185
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
+    static const RgbFit fit = makeRgbFit();
+    launchImageRgb(c->d_fb, c->npix, (double)passes, gamma, fit, c->d_staging, c->stream);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipMemcpyAsync(rgb, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return UBDPT_SUCCESS;
+}
+
 int ubdpt_upload_sum(ubdpt_context* c, const double* rgb) {
     if (!c) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);

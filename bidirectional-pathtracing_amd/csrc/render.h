@@ -56,6 +56,10 @@ void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n,
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);
+// sums of the CIE 1931 fits over the three 123 nm bins (uengine/uconverter.cpp:31-76), computed once on the host
+struct RgbFit { d3 sumX, sumY, sumZ; };
+void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma, const RgbFit& fit, double* out,
+                    hipStream_t s);
 
 // LBVH build (bvh.hip). Inputs are device arrays; returns hipSuccess or the failing HIP status.
 // `prims_unsorted` holds one Prim per primitive in object order; on return `prims_out` holds them in

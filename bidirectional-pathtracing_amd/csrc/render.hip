@@ -801,6 +801,26 @@ __global__ void k_deinterleave(const double* in, uint64_t npix, double* fb) {
     fb[2 * npix + i] = in[3 * i + 2];
 }
 
+// UEngine::imageRGB (uengine/uengine.cpp:182-202) per pixel: radiance = sum / passes, CIE XYZ through the
+// three-bin fit sums, XYZ -> linear sRGB, clamp, gamma, clamp (uengine/uconverter.cpp:78-126).
+// Reads the planar sum buffer, writes [y][x][rgb].
+__global__ void k_image_rgb(const double* fb, uint64_t npix, double passes, double gamma, RgbFit fit, double* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    d3 radiance = mk3(fb[i], fb[npix + i], fb[2 * npix + i]) / passes;
+    d3 r123 = radiance / 123.0;
+    d3 xyz = mk3(dot(r123, fit.sumX), dot(r123, fit.sumY), dot(r123, fit.sumZ));
+    double c[3] = {dot(xyz, mk3(3.2404542, -1.5371385, -0.4985314)), dot(xyz, mk3(-0.9692660, 1.8760108, 0.0415560)),
+                   dot(xyz, mk3(0.0556434, -0.2040259, 1.0572252))};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double v = fmin(fmax(c[k], 0.0), 1.0);
+        if (v <= 0.0031308) v *= 12.92;
+        else v = 1.055 * pow(v, 1.0 / gamma) - 0.055;
+        out[3 * i + k] = fmin(fmax(v, 0.0), 1.0);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
@@ -878,6 +898,10 @@ void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t 
 }
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s) {
     hipLaunchKernelGGL(k_deinterleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, in, npix, fb);
+}
+void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma, const RgbFit& fit, double* out,
+                    hipStream_t s) {
+    hipLaunchKernelGGL(k_image_rgb, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, passes, gamma, fit, out);
 }
 
 }  // namespace ub

@@ -190,6 +190,18 @@ void HipEngine::stop() {
     if (m_renderer) m_renderer->stop();
 }
 
+Result HipEngine::imageRGB(std::vector<double>& img_data, double gamma, size_t& img_width, size_t& img_height) {
+    if ((m_curr_pass == 0) || (gamma <= 0) || !m_buffers[m_read] || !m_renderer) return Result::UNoData;
+    img_width = m_params.img_res_x;
+    img_height = m_params.img_res_y;
+    img_data.resize(img_width * img_height * 3);
+    // the host buffer is the engine's truth (pass-by-pass rendering leaves only the last pass on the device)
+    if (!m_renderer->uploadSum(m_buffers[m_read].get())) return Result::UError;
+    int st = ubdpt_image_rgb(m_renderer->context(), m_curr_pass, gamma, img_data.data());
+    if (st == UBDPT_NO_DATA) return Result::UNoData;
+    return st == UBDPT_SUCCESS ? Result::USuccess : Result::UError;
+}
+
 }  // namespace uhip
 
 // ---- C shim over the classes (used by the Python tests; a C++ caller uses the classes directly) ---------
@@ -221,6 +233,15 @@ int uhip_engine_sum(uhip_engine* e, double* out) {
     if (!s || !out) return (int)uhip::Result::UNoData;
     std::memcpy(out, s->ptr(), sizeof(double) * 3 * s->width() * s->height());
     return (int)uhip::Result::USuccess;
+}
+int uhip_engine_image_rgb(uhip_engine* e, double gamma, double* out, size_t capacity) {
+    std::vector<double> img;
+    size_t w = 0, h = 0;
+    int r = (int)e->engine.imageRGB(img, gamma, w, h);
+    if (r != 0) return r;
+    if (!out || capacity < img.size()) return (int)uhip::Result::UError;
+    std::memcpy(out, img.data(), sizeof(double) * img.size());
+    return r;
 }
 int uhip_engine_save(uhip_engine* e, const char* filename) { return (int)e->engine.saveRendering(filename); }
 int uhip_engine_load(uhip_engine* e, const char* filename, ubdpt_render_params* params, int* type, size_t* curr_pass) {

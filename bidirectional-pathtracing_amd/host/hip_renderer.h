@@ -115,6 +115,8 @@ public:
     // n passes with the sum resident on the device; the host sum buffer is refreshed once at the end
     Result renderPasses(size_t n);
     void stop();                                                                                      // :204-208
+    // :182-202 with URgbFormat::sRGB: H x W x 3 display values in [0,1]; the conversion runs on the device
+    Result imageRGB(std::vector<double>& img_data, double gamma, size_t& img_width, size_t& img_height);
     size_t currPass() const { return m_curr_pass; }
     const SumBuffer* sum() const { return m_buffers[m_read].get(); }   // radiance = sum / currPass (uengine.cpp:197)
     HipRenderer* renderer() { return m_renderer.get(); }

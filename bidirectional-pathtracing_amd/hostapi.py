@@ -16,7 +16,8 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_double)
 
 EXPORTS = ["uhip_engine_create", "uhip_engine_destroy", "uhip_engine_set_scene", "uhip_engine_new_rendering",
            "uhip_engine_render_pass", "uhip_engine_render_passes", "uhip_engine_stop", "uhip_engine_curr_pass",
-           "uhip_engine_sum", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write", "uhip_ur_read"]
+           "uhip_engine_sum", "uhip_engine_image_rgb", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write",
+           "uhip_ur_read"]
 
 _lib = None
 
@@ -42,6 +43,7 @@ def load_library():
         lib.uhip_engine_curr_pass.restype = C.c_size_t
         lib.uhip_engine_curr_pass.argtypes = [vp]
         lib.uhip_engine_sum.argtypes = [vp, vp]
+        lib.uhip_engine_image_rgb.argtypes = [vp, C.c_double, vp, C.c_size_t]
         lib.uhip_engine_save.argtypes = [vp, C.c_char_p]
         lib.uhip_engine_load.argtypes = [vp, C.c_char_p, C.POINTER(capi.RenderParams), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
         lib.uhip_ur_write.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(capi.RenderParams), C.c_int, vp]
@@ -99,6 +101,12 @@ class Engine:
         out = np.zeros((int(self.params.img_res_y), int(self.params.img_res_x), 3))
         st = self.lib.uhip_engine_sum(self.h, out.ctypes.data)
         return out if st == USUCCESS else None
+
+    def image_rgb(self, gamma=2.2):
+        """(status, H x W x 3 display values or None)."""
+        out = np.zeros((int(self.params.img_res_y), int(self.params.img_res_x), 3))
+        st = self.lib.uhip_engine_image_rgb(self.h, gamma, out.ctypes.data, out.size)
+        return st, (out if st == USUCCESS else None)
 
     def save(self, path):
         return self.lib.uhip_engine_save(self.h, path.encode())

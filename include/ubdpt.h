@@ -213,6 +213,14 @@ int ubdpt_render_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_pass
                         uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
 
 /*
+ * UEngine::imageRGB (uengine/uengine.cpp:182-202) on the device sum buffer: radiance = sum / passes,
+ * then UConverter::radianceToRGB (uengine/uconverter.cpp:78-126: CIE XYZ fit, sRGB matrix, gamma).
+ * rgb receives H x W x 3 doubles in [0,1], row-major like the sum buffer. Returns UBDPT_NO_DATA when
+ * passes == 0 or gamma <= 0, as the reference does. Only W*H*3 display values cross PCIe.
+ */
+int ubdpt_image_rgb(ubdpt_context* ctx, uint64_t passes, double gamma, double* rgb);
+
+/*
  * The same work as ubdpt_render_passes, enqueued without waiting for the GPU: consecutive calls keep
  * the device busy across call boundaries (the reference's counterpart is UEngine calling
  * renderPass again as soon as the previous pass returned, uapp/appmanager.cpp:486).

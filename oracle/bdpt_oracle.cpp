@@ -1343,4 +1343,63 @@ int oracle_sample_map(int which, uint64_t num_strata, uint64_t stratum, double u
     return UBDPT_INVALID_ARG;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* UEngine::imageRGB (uengine/uengine.cpp:182-202) with UConverter (uengine/uconverter.cpp)     */
+/* ------------------------------------------------------------------------------------------ */
+namespace {
+/* uconverter.cpp:3-29: multi-lobe Gaussian fits of the CIE 1931 colour matching functions */
+double xFit_1931(double wave) {
+    double t1 = (wave - 442.0) * ((wave < 442.0) ? 0.0624 : 0.0374);
+    double t2 = (wave - 599.8) * ((wave < 599.8) ? 0.0264 : 0.0323);
+    double t3 = (wave - 501.1) * ((wave < 501.1) ? 0.0490 : 0.0382);
+    return 0.362 * std::exp(-0.5 * t1 * t1) + 1.056 * std::exp(-0.5 * t2 * t2) - 0.065 * std::exp(-0.5 * t3 * t3);
+}
+double yFit_1931(double wave) {
+    double t1 = (wave - 568.8) * ((wave < 568.8) ? 0.0213 : 0.0247);
+    double t2 = (wave - 530.9) * ((wave < 530.9) ? 0.0613 : 0.0322);
+    return 0.821 * std::exp(-0.5 * t1 * t1) + 0.286 * std::exp(-0.5 * t2 * t2);
+}
+double zFit_1931(double wave) {
+    double t1 = (wave - 437.0) * ((wave < 437.0) ? 0.0845 : 0.0278);
+    double t2 = (wave - 459.0) * ((wave < 459.0) ? 0.0385 : 0.0725);
+    return 1.217 * std::exp(-0.5 * t1 * t1) + 0.681 * std::exp(-0.5 * t2 * t2);
+}
+/* uconverter.cpp:31-76: three 123 nm bins (r: 626.., g: 503.., b: 380..), 1 nm steps */
+dvec3 xyzSum(double (*fit)(double)) {
+    dvec3 sum = {0, 0, 0};
+    for (size_t l = 0; l < 123; l++) {
+        sum.x += fit(626 + l);
+        sum.y += fit(503 + l);
+        sum.z += fit(380 + l);
+    }
+    return sum;
+}
+/* uconverter.cpp:91-126 */
+dvec3 radianceToSRGB(dvec3 radiance, double gamma) {
+    static const dvec3 sumX = xyzSum(xFit_1931), sumY = xyzSum(yFit_1931), sumZ = xyzSum(zFit_1931);
+    dvec3 xyz = {dot(radiance / 123.0, sumX), dot(radiance / 123.0, sumY), dot(radiance / 123.0, sumZ)};
+    /* xyz * T with T's columns as written in the constructor (row vector times matrix) */
+    dvec3 rgb = {dot(xyz, dvec3{3.2404542, -1.5371385, -0.4985314}), dot(xyz, dvec3{-0.9692660, 1.8760108, 0.0415560}),
+                 dot(xyz, dvec3{0.0556434, -0.2040259, 1.0572252})};
+    double c[3] = {rgb.x, rgb.y, rgb.z};
+    for (int k = 0; k < 3; k++) {
+        c[k] = std::fmin(std::fmax(c[k], 0.0), 1.0);
+        if (c[k] <= 0.0031308) c[k] *= 12.92;
+        else c[k] = 1.055 * std::pow(c[k], 1.0 / gamma) - 0.055;
+        c[k] = std::fmin(std::fmax(c[k], 0.0), 1.0);
+    }
+    return {c[0], c[1], c[2]};
+}
+}  // namespace
+
+int oracle_image_rgb(const double* sum, size_t npix, uint64_t curr_pass, double gamma, double* rgb) {
+    if ((curr_pass == 0) || (gamma <= 0) || !sum || !rgb) return UBDPT_NO_DATA; /* uengine.cpp:184-185 */
+    for (size_t p = 0; p < npix; p++) {
+        dvec3 radiance = dvec3{sum[3 * p], sum[3 * p + 1], sum[3 * p + 2]} / static_cast<double>(curr_pass);
+        dvec3 c = radianceToSRGB(radiance, gamma);
+        rgb[3 * p] = c.x; rgb[3 * p + 1] = c.y; rgb[3 * p + 2] = c.z;
+    }
+    return UBDPT_SUCCESS;
+}
+
 } /* extern "C" */

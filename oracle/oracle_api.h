@@ -82,6 +82,10 @@ double oracle_uniform(uint64_t seed, uint64_t pass, uint64_t pixel, uint32_t str
  *        5 triangle barycentric map (u1, u2) -> (1-s, s-m, m). */
 int  oracle_sample_map(int which, uint64_t num_strata, uint64_t stratum, double u1, double u2, double out[3]);
 
+/* UEngine::imageRGB (uengine/uengine.cpp:182-202): radiance = sum / curr_pass, CIE XYZ fit, sRGB with
+ * gamma (uengine/uconverter.cpp). sum and rgb: npix x 3 doubles. UBDPT_NO_DATA when curr_pass == 0 or gamma <= 0. */
+int  oracle_image_rgb(const double* sum, size_t npix, uint64_t curr_pass, double gamma, double* rgb);
+
 #ifdef __cplusplus
 }
 #endif

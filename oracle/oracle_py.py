@@ -57,6 +57,7 @@ def lib():
         l.oracle_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
         l.oracle_uniform.restype = C.c_double
         l.oracle_sample_map.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_double, C.c_double, vp]
+        l.oracle_image_rgb.argtypes = [vp, C.c_size_t, C.c_uint64, C.c_double, vp]
         _lib = l
     return _lib
 
@@ -162,3 +163,11 @@ def sample_map(which, num_strata, stratum, u1, u2):
     out = np.zeros(3)
     assert lib().oracle_sample_map(which, num_strata, stratum, u1, u2, out.ctypes.data) == 0
     return out
+
+
+def image_rgb(sum_img, curr_pass, gamma=2.2):
+    """UEngine::imageRGB on an H x W x 3 sum image; None when the reference reports UNoData."""
+    sum_img = np.ascontiguousarray(sum_img, np.float64)
+    out = np.zeros_like(sum_img)
+    st = lib().oracle_image_rgb(sum_img.ctypes.data, sum_img.size // 3, curr_pass, gamma, out.ctypes.data)
+    return out if st == 0 else None
