@@ -111,7 +111,7 @@ struct ubdpt_context {
     double* d_staging = nullptr;  // interleaved, npix * 3
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
-    uint32_t wf_depth = 6;        // bounces run as wavefront launches before the tail loop
+    uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
     unsigned long long pair_capacity = 0;
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
@@ -434,18 +434,25 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8;
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
-            uint64_t target = 1ull << 20;
+            uint64_t target = 1ull << 22;  // measured: throughput still rises up to ~4 M pixel-samples per batch
             pif = (uint32_t)((target + c->npix - 1) / c->npix);
             if (pif < 1) pif = 1;
             if (pif > 64) pif = 64;
         }
-        while (pif > 1 && per_path * c->npix * pif > (24ull << 30)) pif--;
+        uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 4) : 2;
+        // the batch lanes together may take half of the memory that is free now (288 GB parts: ~140 GB)
+        size_t mem_free = 0, mem_total = 0;
+        if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
+        const uint64_t lane_budget = std::max<uint64_t>(1ull << 30, (uint64_t)mem_free / 2 / nstreams);
+        while (pif > 1 && (per_path + 1024) * c->npix * pif > lane_budget) pif--;
+        // the packed queue entries hold a subpath id in 29 bits
+        while (pif > 1 && 2 * c->npix * pif >= (1ull << 29) - 1) pif--;
+        // one pass of a very large image may already exceed a lane's share: then a single lane gets the whole budget
+        if ((per_path + 1024) * c->npix * pif > lane_budget) nstreams = 1;
         c->passes_in_flight = pif;
         c->cap_paths = c->npix * pif;
-        // the packed queue entries hold a subpath id in 29 bits
         if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
-        uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 4) : 2;
-        c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 6;
+        c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 8;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));

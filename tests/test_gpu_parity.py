@@ -284,3 +284,21 @@ def test_large_mesh_lbvh_equals_linear_scan(n_tris, n_rays):
     for f in ("d", "pos", "Ng", "Ns", "Ts", "Bs", "tex_u", "tex_v"):
         assert np.array_equal(h0[f][m].view(np.uint64), h1[f][m].view(np.uint64)), f
     assert np.array_equal(v0, v1) and 0 < v1.sum() < n_rays
+
+
+@pytest.mark.parametrize("name", ["C1", "C2"])
+def test_relmse_gate_against_independent_reference_seeds(oracle_mod, name):
+    """The statistical gate for images: at equal spp the backend's image must be as close to an
+    independently seeded CPU image as two CPU images are to each other:
+    relMSE(GPU(seed 3), REF(seed 1)) <= 1.5 * relMSE(REF(seed 2), REF(seed 1)), channel means within 1 %."""
+    n = 32
+    scene, ctx, orc = make_pair(oracle_mod, name, w=64, h=64)
+    ref1 = orc.render_passes(0, n, 1, num_threads=8) / n
+    ref2 = orc.render_passes(0, n, 2, num_threads=8) / n
+    ctx.render_passes(0, n, 3)
+    gpu = ctx.read_sum() / n
+    ctx.close()
+    noise = rel_mse(ref2, ref1)
+    assert rel_mse(gpu, ref1) <= 1.5 * noise
+    m_gpu, m_ref = gpu.reshape(-1, 3).mean(0), 0.5 * (ref1 + ref2).reshape(-1, 3).mean(0)
+    assert np.all(np.abs(m_gpu - m_ref) / m_ref < 0.01)
