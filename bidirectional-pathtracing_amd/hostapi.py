@@ -17,7 +17,8 @@ PROGRESS_CB = C.CFUNCTYPE(None, C.c_double)
 EXPORTS = ["uhip_engine_create", "uhip_engine_destroy", "uhip_engine_set_scene", "uhip_engine_new_rendering",
            "uhip_engine_render_pass", "uhip_engine_render_passes", "uhip_engine_stop", "uhip_engine_curr_pass",
            "uhip_engine_sum", "uhip_engine_image_rgb", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write",
-           "uhip_ur_read"]
+           "uhip_ur_read", "uhip_scene_load_xml", "uhip_scene_ok", "uhip_scene_error", "uhip_scene_desc",
+           "uhip_scene_free"]
 
 _lib = None
 
@@ -49,8 +50,54 @@ def load_library():
         lib.uhip_ur_write.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(capi.RenderParams), C.c_int, vp]
         lib.uhip_ur_read.argtypes = [C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(capi.RenderParams), C.POINTER(C.c_int), vp,
                                      C.c_size_t]
+        lib.uhip_scene_load_xml.restype = vp
+        lib.uhip_scene_load_xml.argtypes = [C.c_char_p, C.c_char_p]
+        lib.uhip_scene_ok.argtypes = [vp]
+        lib.uhip_scene_error.restype = C.c_char_p
+        lib.uhip_scene_error.argtypes = [vp]
+        lib.uhip_scene_desc.restype = C.POINTER(capi.SceneDesc)
+        lib.uhip_scene_desc.argtypes = [vp]
+        lib.uhip_scene_free.restype = None
+        lib.uhip_scene_free.argtypes = [vp]
         _lib = lib
     return _lib
+
+
+class XmlScene:
+    """A scene read by the C++ loader (uhip::LoadedScene) from the reference's XML schema. Has the
+    attributes of capi.FlatScene that Context / Oracle / Engine use."""
+
+    def __init__(self, xml_path, base_dir=""):
+        self.lib = load_library()
+        self.h = self.lib.uhip_scene_load_xml(xml_path.encode(), base_dir.encode())
+        if not self.lib.uhip_scene_ok(self.h):
+            msg = self.lib.uhip_scene_error(self.h).decode()
+            self.lib.uhip_scene_free(self.h)
+            self.h = None
+            raise RuntimeError(msg)
+        self.desc = self.lib.uhip_scene_desc(self.h).contents
+        self.n_objects = self.desc.num_objects
+        self.n_textures = self.desc.num_textures
+        self.objects = self.desc.objects
+        self.num_faces = self.desc.num_faces
+
+    def vertices(self):
+        n = 3 * int(self.desc.num_faces)
+        if n == 0:
+            return np.zeros(0, capi.MESH_VERTEX_DTYPE)
+        buf = C.cast(self.desc.vertices, C.POINTER(C.c_char * (n * 44))).contents
+        return np.frombuffer(buf, capi.MESH_VERTEX_DTYPE, n).copy()
+
+    def close(self):
+        if self.h:
+            self.lib.uhip_scene_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def ur_write(path, curr_pass, params, rtype, sums):
