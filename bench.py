@@ -131,6 +131,7 @@ def main():
                     help="lanes of a wave that must own an (s,t) pair for it to be connected in place (0 = default)")
     ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
+    ap.add_argument("--batch-pixel-samples", type=int, default=0, help="sub-pass batches of this many pixels (0 = whole passes)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal of the N>1 path)")
@@ -178,6 +179,7 @@ def main():
     opt.dense_threshold = args.dense_threshold
     opt.wavefront_depth = args.wavefront_depth
     opt.streams = args.streams
+    opt.batch_pixel_samples = args.batch_pixel_samples
     ctx = capi.Context(scene, params, opt, device)
     sum_dev = torch.zeros((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
 

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <new>
 #include <string>
@@ -130,6 +131,10 @@ struct ubdpt_context {
         uint32_t* d_vis_count = nullptr;
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
+        std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
+        // one marker event per enqueued batch with pending.size() at that point: waiting for the oldest marker
+        // bounds the host's lead over the device without draining the other lanes
+        std::deque<std::pair<hipEvent_t, size_t>> inflight;
     };
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
@@ -161,20 +166,67 @@ struct ubdpt_context {
         pending.push_back(t);
     }
     void endTimed(hipStream_t stream) { hipEventRecord(pending.back().stop, stream); }
-    void collectTimed() {  // call after the stream is synchronised
-        for (auto& t : pending) {
+    // folds the first n entries of v (whose events have completed) into the per-kernel statistics
+    void foldTimed(std::vector<TimedLaunch>& v, size_t n) {
+        for (size_t k = 0; k < n && k < v.size(); k++) {
+            TimedLaunch& t = v[k];
             float ms = 0;
             if (hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
                 kernel_ms[t.kernel] += ms; kernel_units[t.kernel] += t.units; kernel_launches[t.kernel]++;
             }
             event_pool.emplace_back(t.start, t.stop);
         }
-        pending.clear();
+        v.erase(v.begin(), v.begin() + std::min(n, v.size()));
+    }
+    void collectTimed() { foldTimed(pending, pending.size()); }  // call after the stream is synchronised
+    void beginTimedLane(BatchLane& b, int kernel, double units) {
+        TimedLaunch t;
+        if (!event_pool.empty()) { t.start = event_pool.back().first; t.stop = event_pool.back().second; event_pool.pop_back(); }
+        else { hipEventCreate(&t.start); hipEventCreate(&t.stop); }
+        t.kernel = kernel; t.units = units;
+        hipEventRecord(t.start, b.stream);
+        b.pending.push_back(t);
+    }
+    void endTimedLane(BatchLane& b) { hipEventRecord(b.pending.back().stop, b.stream); }
+    std::vector<hipEvent_t> marker_pool;
+    void markBatch(BatchLane& b) {
+        hipEvent_t ev;
+        if (!marker_pool.empty()) { ev = marker_pool.back(); marker_pool.pop_back(); }
+        else hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        hipEventRecord(ev, b.stream);
+        b.inflight.emplace_back(ev, b.pending.size());
+    }
+    // waits until at most max_inflight batches of the lane are unfinished
+    hipError_t throttle(BatchLane& b, size_t max_inflight) {
+        while (b.inflight.size() > max_inflight) {
+            auto front = b.inflight.front();
+            hipError_t e = hipEventSynchronize(front.first);
+            if (e != hipSuccess) return e;
+            foldTimed(b.pending, front.second);
+            b.inflight.pop_front();
+            for (auto& f : b.inflight) f.second -= front.second;
+            marker_pool.push_back(front.first);
+        }
+        return hipSuccess;
+    }
+    // after every lane stream has been synchronised
+    void collectLanes() {
+        for (auto& b : lanes) {
+            foldTimed(b.pending, b.pending.size());
+            for (auto& f : b.inflight) marker_pool.push_back(f.first);
+            b.inflight.clear();
+        }
     }
     void freeAll() {
         hipSetDevice(device);
         if (stream) hipStreamSynchronize(stream);
         for (auto& t : pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+        for (auto& b : lanes) {
+            if (b.stream) hipStreamSynchronize(b.stream);
+            for (auto& t : b.pending) { hipEventDestroy(t.start); hipEventDestroy(t.stop); }
+            for (auto& f : b.inflight) hipEventDestroy(f.first);
+        }
+        for (auto& e : marker_pool) hipEventDestroy(e);
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
@@ -196,7 +248,7 @@ namespace {
     fprintf(stderr, "ubdpt: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return UBDPT_HIP_ERROR; } } while (0)
 
 int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv) {
-    P.n = n; P.maxv = maxv;
+    P.n = n; P.maxv = maxv; P.count_stride = 1;
     HIPCK(c, hipMalloc((void**)&P.v, sizeof(double) * kVertexDoubles * maxv * n));
     HIPCK(c, hipMalloc((void**)&P.count, sizeof(uint32_t) * n));
     return UBDPT_SUCCESS;
@@ -439,7 +491,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             if (pif < 1) pif = 1;
             if (pif > 64) pif = 64;
         }
-        uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 4) : 2;
+        uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 16) : 2;
         // the batch lanes together may take half of the memory that is free now (288 GB parts: ~140 GB)
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
@@ -451,6 +503,11 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((per_path + 1024) * c->npix * pif > lane_budget) nstreams = 1;
         c->passes_in_flight = pif;
         c->cap_paths = c->npix * pif;
+        // a batch smaller than one pass: a range of pixels of one pass (never across a pass boundary)
+        if (c->opt.batch_pixel_samples && c->opt.batch_pixel_samples < c->npix) {
+            c->passes_in_flight = 1;
+            c->cap_paths = std::max<uint64_t>(4096, (c->opt.batch_pixel_samples + 255) / 256 * 256);
+        }
         if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
         c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 8;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
@@ -508,6 +565,7 @@ static int finishPending(ubdpt_context* c) {
     if (!c->work_pending) return UBDPT_SUCCESS;
     for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
     c->work_pending = false;
+    c->collectLanes();
     c->collectTimed();
     int fc = fetchCounters(c);
     if (fc != UBDPT_SUCCESS) return fc;
@@ -532,18 +590,23 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
     uint32_t done = 0;
     int status = UBDPT_SUCCESS;
     uint64_t& batch = c->next_batch;
-    while (done < n_passes) {
-        if (c->stop.load()) { status = UBDPT_STOPPED; break; }
-        uint32_t nb = n_passes - done;
-        if (nb > c->passes_in_flight) nb = c->passes_in_flight;
+    // pixel-samples of this call in (pass, pixel) order; a batch is a contiguous range of them: whole passes, or
+    // (when the batch size is below one pass) a range of pixels inside one pass
+    const uint64_t total_paths = (uint64_t)n_passes * c->npix;
+    uint64_t pos = 0;
+    while (pos < total_paths) {
+        if (pos % c->npix == 0 && c->stop.load()) { status = UBDPT_STOPPED; break; }
+        uint64_t nbatch = std::min<uint64_t>(c->cap_paths, total_paths - pos);
+        if (c->cap_paths < c->npix) nbatch = std::min<uint64_t>(nbatch, c->npix - pos % c->npix);
         ubdpt_context::BatchLane& B = c->lanes[batch % c->lanes.size()];
         hipStream_t sm = B.stream;
         RenderArgs A;
         A.S = c->S;
         A.E = B.E; A.L = B.L;
-        A.E.n = A.L.n = c->npix * nb;
+        A.E.n = A.L.n = nbatch;
         A.fb = c->d_fb;
-        A.first_pass = first_pass + (uint64_t)done * pass_stride;
+        A.first_pass = first_pass;
+        A.path_offset = pos;
         A.pass_stride = pass_stride;
         A.seed = seed;
         A.ovf = B.d_ovf; A.ovf_stride = A.E.n;
@@ -560,10 +623,18 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         //           2 = per-path subpath kernels + global pair queue, one kernel per pair
         //           3 = wavefront with fused trace+shade bounce kernel + in-place dense / queued sparse pairs
         const uint32_t pl = c->opt.pipeline;
+        if (pl == 0 || pl == 3) {
+            // wavefront pipelines: the count word of subpath `id` is the spare eighth double of its carry record
+            // (eye subpaths first, then the light subpaths), so trace and shade touch one line less per subpath
+            const uint32_t stride = kCarryDoubles * (uint32_t)(sizeof(double) / sizeof(uint32_t));
+            A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + (kCarryDoubles - 1));
+            A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + (kCarryDoubles - 1));
+            A.E.count_stride = A.L.count_stride = stride;
+        }
         const uint32_t D = c->wf_depth;
         auto run = [&](int kernel, double u, auto&& launch) {
             A.counters = c->d_counters + kernel * kNumCounters;
-            c->beginTimed(kernel, u, sm); launch(); c->endTimed(sm);
+            c->beginTimedLane(B, kernel, u); launch(); c->endTimedLane(B);
         };
         if (pl == 0 || pl == 3) {
             HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
@@ -605,15 +676,15 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             }
         }
         HIPCK(c, hipGetLastError());
-        done += nb;
+        pos += nbatch;
         batch++;
-        // keep at most a few batches queued per lane so that a stop request is honoured promptly
-        if (batch % (4 * c->lanes.size()) == 0)
-        {
-            for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
-            c->collectTimed();
-        }
+        // keep at most a few batches (about 16 M pixel-samples) queued per lane, so that a stop request is
+        // honoured promptly and the host does not run arbitrarily far ahead of the device
+        c->markBatch(B);
+        const size_t max_inflight = (size_t)std::max<uint64_t>(2, std::min<uint64_t>(64, (16ull << 20) / std::max<uint64_t>(1, c->cap_paths)));
+        HIPCK(c, c->throttle(B, max_inflight));
     }
+    done = (uint32_t)(pos / c->npix);
     c->stats.passes += done;
     c->stats.pixel_samples += (uint64_t)done * c->npix;
     if (passes_done) *passes_done = done;

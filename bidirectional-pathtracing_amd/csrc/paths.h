@@ -25,9 +25,10 @@ DEV uint32_t specularBit(uint32_t k, bool specular) { return (specular && k < kM
 
 struct PathStore {
     double* v;        // records of kVertexDoubles doubles
-    uint32_t* count;  // [n] count word per subpath
+    uint32_t* count;  // count word of subpath i at count[i * count_stride]
     uint64_t n;
     uint32_t maxv;
+    uint32_t count_stride;
 
 #ifdef UBDPT_PATH_MAJOR
     DEV uint64_t rec(uint32_t slot, uint64_t i) const { return (i * maxv + slot) * kVertexDoubles; }
@@ -49,7 +50,11 @@ struct PathStore {
         v[at(f, slot, i)] = x.x; v[at(f + 1, slot, i)] = x.y; v[at(f + 2, slot, i)] = x.z;
     }
     DEV bool specular(uint32_t slot, uint64_t i) const { return (flg(slot, i) >> 8) & 1; }
-    DEV uint32_t cnt(uint64_t i) const { return count[i] & 0xffu; }
+    // the count words may be interleaved with other per-subpath state (count_stride words apart): the
+    // wavefront kernels keep them inside the carry records, which they have to touch anyway
+    DEV uint32_t meta(uint64_t i) const { return count[i * count_stride]; }
+    DEV void setMeta(uint64_t i, uint32_t m) const { count[i * count_stride] = m; }
+    DEV uint32_t cnt(uint64_t i) const { return meta(i) & 0xffu; }
     // may vertex k of subpath i (count word `meta`) be connected, i.e. is it not specular?
     DEV bool connectable(uint32_t meta, uint32_t k, uint64_t i) const {
         return k < kMaskedVertices ? !((meta >> (8 + k)) & 1u) : !specular(k, i);

@@ -13,6 +13,7 @@ struct RenderArgs {
     PathStore E, L;        // eye / light subpath vertices of the batch
     double* fb;            // planar sum buffer: R[npix], G[npix], B[npix]
     uint64_t first_pass, pass_stride, seed;
+    uint64_t path_offset;  // index of the batch's first pixel-sample among the call's n_passes * npix
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
     uint64_t ovf_stride;
     unsigned long long* counters;

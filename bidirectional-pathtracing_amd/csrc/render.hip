@@ -70,9 +70,12 @@ DEV void fbAdd(double* fb, uint64_t npix, uint64_t pixel, d3 v) {
 }
 
 DEV void decodePath(const RenderArgs& A, uint64_t gid, uint64_t& pass, uint64_t& pixel, uint32_t& px, uint32_t& py) {
+    // a batch is a contiguous range of the call's pixel-samples in (pass, pixel) order; it need not start or
+    // end on a pass boundary
     uint64_t npix = (uint64_t)A.S.img_res_x * A.S.img_res_y;
-    uint64_t pi = gid / npix;
-    pixel = gid - pi * npix;
+    uint64_t g = A.path_offset + gid;
+    uint64_t pi = g / npix;
+    pixel = g - pi * npix;
     pass = A.first_pass + pi * A.pass_stride;
     py = (uint32_t)(pixel / A.S.img_res_x);
     px = (uint32_t)(pixel - (uint64_t)py * A.S.img_res_x);
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
             E.st(F_PL, n - 2, gid, q * p_psa * G_prev);
         }
     }
-    E.count[gid] = n | smask;
+    E.setMeta(gid, n | smask);
     if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
@@ -364,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
             }
         }
     }
-    L.count[gid] = n | smask;
+    L.setMeta(gid, n | smask);
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -493,7 +496,7 @@ DEV void pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
         if (STATS) ty.splat++;
         fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
     } else
-        fbAdd(A.fb, npix, i % npix, vl.a * ve.a * c * w);
+        fbAdd(A.fb, npix, (A.path_offset + i) % npix, vl.a * ve.a * c * w);
 }
 
 template <bool STATS>
@@ -532,7 +535,7 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
         if (STATS) ty.splat++;
         fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
     } else
-        fbAdd(A.fb, npix, i % npix, vl.a * ve.a * c * w);
+        fbAdd(A.fb, npix, (A.path_offset + i) % npix, vl.a * ve.a * c * w);
 }
 
 // One lane per pixel-sample: appends its connectable (s,t) pairs to the pair queue. The specular
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     const PathStore& L = A.L;
     uint32_t mE = 0, mL = 0, nE = 0, nL = 0, cE = 0, cL = 0;
     if (active) {
-        mE = E.count[gid]; mL = L.count[gid];
+        mE = E.meta(gid); mL = L.meta(gid);
         nE = mE & 0xff; nL = mL & 0xff;
         for (uint32_t t = 0; t < nE; t++) cE += E.connectable(mE, t, gid) ? 1u : 0u;
         for (uint32_t s = 0; s < nL; s++) cL += L.connectable(mL, s, gid) ? 1u : 0u;

@@ -164,7 +164,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     }
     storeVertex(P, n, i, nv);
     n++;
-    P.count[i] = ((P.count[i] & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n;
+    P.setMeta(i, ((P.meta(i) & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n);
     ray.o = nv.sp.pos;
     ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
     cy.dir = ray.d; cy.fs = fs; cy.p_psa = p_psa;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             lens.p_light_A = 0;
             lens.specular = false;
             storeVertex(A.E, 0, i, lens);
-            A.E.count[i] = 1;
+            A.E.setMeta(i, 1);
             d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
             d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
                                   1.0 - ((double)py + pp.y) * S.pixel_height, S.image_plane_distance);
@@ -230,13 +230,13 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             ev.p_eye_A = 0;
             ev.specular = false;
             storeVertex(A.L, 0, i, ev);
-            A.L.count[i] = 1;
+            A.L.setMeta(i, 1);
             d3 dirT = samplePosHemUniform(rng(DIM_EMIT_ANGLE), rng(DIM_EMIT_V));
             cy.dir = float_tnb_mul(ev.sp.Ts, ev.sp.Ns, ev.sp.Bs, dirT);
             cy.p_psa = dirT.y;
             live = true;
         } else {
-            A.L.count[i] = 0;
+            A.L.setMeta(i, 0);
         }
         if (live) storeCarry(A, id, cy);
     }

@@ -124,7 +124,9 @@ typedef struct ubdpt_options {
     uint32_t pipeline;          /* 0 = default pipeline; 1..3 select variants kept for comparison */
     uint32_t dense_threshold;   /* pipeline 3: lanes of a wave that must own an (s,t) pair to connect it in place; 0 -> 40 */
     uint32_t wavefront_depth;   /* bounces run as wavefront launches before the per-lane tail loop; 0 -> default, max 30 */
-    uint32_t streams;           /* batches in flight on separate HIP streams; 0 -> default, max 4 */
+    uint32_t streams;           /* batches in flight on separate HIP streams; 0 -> default, max 16 */
+    uint32_t batch_pixel_samples; /* non-zero and below one pass: a batch is this many pixels of one pass
+                                     (overrides passes_in_flight); small batches keep the path vertices cache-resident */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */

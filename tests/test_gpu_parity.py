@@ -233,6 +233,28 @@ def test_passes_in_flight_does_not_change_the_result(oracle_mod):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("pipeline", [0, 2])
+def test_sub_pass_batches_and_many_streams_do_not_change_the_result(pipeline):
+    """Batches of a few thousand pixels of one pass (never across a pass boundary), spread over 5 streams,
+    against whole-pass batches on one stream; also through the asynchronous entry points."""
+    scene = SCENES["C2"]()
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(80, 80)
+    imgs = []
+    for batch, streams in ((0, 1), (5000, 5)):
+        opt = capi.Options()
+        opt.pipeline = pipeline
+        opt.batch_pixel_samples = batch
+        opt.streams = streams
+        with capi.Context(scene, params, opt) as ctx:
+            ctx.enqueue_passes(0, 2, SEED)
+            ctx.enqueue_passes(2, 3, SEED)
+            ctx.synchronize()
+            imgs.append(ctx.read_sum())
+            assert ctx.stats()["passes"] == 5
+    assert imgs[0].sum() > 0 and np.allclose(imgs[0], imgs[1], rtol=1e-12, atol=1e-12)
+
+
 def test_path_cap_matches_oracle(oracle_mod):
     """With a small vertex cap both sides truncate the same subpaths."""
     scene, ctx, orc = make_pair(oracle_mod, "C2", w=32, h=32, maxv=4, stats=1)
