@@ -467,9 +467,10 @@ DEV bool pairVisible(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     return visible<STATS>(S, lpos, epos, st, ty);
 }
 
-// Second half: connection factor, MIS weight, accumulation (no ray is traced here).
+// Second half: connection factor and MIS weight (no ray is traced here). Returns the contribution and the
+// pixel it belongs to; false when the pair contributes nothing.
 template <bool STATS>
-DEV void pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally& ty) {
+DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally& ty, uint64_t& pixel, d3& value) {
     const DScene& S = A.S;
     const PathStore& E = A.E;
     const PathStore& L = A.L;
@@ -479,24 +480,26 @@ DEV void pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
     loadConn(E, t - 1, i, ve);
     uint32_t tx = 0, tyy = 0;
     if (t == 1) {
-        if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) return;
+        if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) return false;
     }
     d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
     d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
     d3 c;
     double w;
     if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
-        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, c, w)) return;
+        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, c, w)) return false;
     } else {
-        if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return;
+        if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return false;
         w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
     }
     if (STATS) { ty.conn++; ty.fb++; }
     if (t == 1) {
         if (STATS) ty.splat++;
-        fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
+        pixel = (uint64_t)tyy * S.img_res_x + tx;
     } else
-        fbAdd(A.fb, npix, (A.path_offset + i) % npix, vl.a * ve.a * c * w);
+        pixel = (A.path_offset + i) % npix;
+    value = vl.a * ve.a * c * w;
+    return true;
 }
 
 template <bool STATS>
@@ -574,10 +577,12 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     unsigned long long pos = s_base + (incl - cnt);
     for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
     if (pos + cnt <= A.pair_capacity) {
-        for (uint32_t s = 1; s <= nL; s++) {
-            if (!L.connectable(mL, s - 1, gid)) continue;
-            for (uint32_t t = 1; t <= nE; t++) {
-                if (!E.connectable(mE, t - 1, gid)) continue;
+        // t-major: the t = 1 pairs (splats into other pixels) first, then every pair that lands in the
+        // pixel-sample's own pixel next to each other, so that k_pair_eval can add them up before its atomics
+        for (uint32_t t = 1; t <= nE; t++) {
+            if (!E.connectable(mE, t - 1, gid)) continue;
+            for (uint32_t s = 1; s <= nL; s++) {
+                if (!L.connectable(mL, s - 1, gid)) continue;
                 A.pairs[pos++] = packPair(gid, s, t);
             }
         }

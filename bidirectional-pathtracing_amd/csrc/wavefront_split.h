@@ -192,15 +192,39 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(Rend
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
+// Adjacent lanes mostly hold pairs of one pixel-sample that land in the same pixel (the queue is in
+// pixel-sample order, k_pair_enum emits the own-pixel pairs of a pixel-sample next to each other):
+// runs of equal target pixels are summed with shuffles and the first lane of a run issues the three
+// atomics. Atomic throughput, not arithmetic, limits this kernel.
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_pair_eval(RenderArgs A) {
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t total = *A.vis_count;
+    const uint64_t npix = (uint64_t)A.S.img_res_x * A.S.img_res_y;
     Tally ty;
-    for (uint64_t j = gid; j < total; j += nthreads) {
-        uint64_t p = A.vis_pairs[j];
-        pairEval<STATS>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), ty);
+    for (uint64_t base = gid - lane; base < total; base += nthreads) {  // wave-uniform trip count
+        const uint64_t j = base + lane;
+        uint64_t key = ~0ULL;  // target pixel, ~0: nothing to add
+        d3 v = mk3(0, 0, 0);
+        if (j < total) {
+            uint64_t p = A.vis_pairs[j];
+            uint64_t pixel;
+            if (pairEval<STATS>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), ty, pixel, v)) key = pixel;
+        }
+        // runs of adjacent lanes with the same target: a run starts where the key changes
+        const uint64_t prev = __shfl_up(key, 1, 64);
+        const bool boundary = lane == 0 || prev != key;
+        const unsigned long long starts = __ballot(boundary);
+        const int run = 63 - __clzll((long long)(starts & ((2ULL << lane) - 1ULL)));  // first lane of this lane's run
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int r2 = __shfl_down(run, off, 64);
+            const double x = __shfl_down(v.x, off, 64), y = __shfl_down(v.y, off, 64), z = __shfl_down(v.z, off, 64);
+            if (lane + off < 64 && r2 == run) { v.x += x; v.y += y; v.z += z; }
+        }
+        if (boundary && key != ~0ULL) fbAdd(A.fb, npix, key, v);
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
 }
