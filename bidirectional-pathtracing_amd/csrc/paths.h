@@ -6,7 +6,9 @@
 // from HBM; with one record per vertex every fetched line is data of the vertex that asked for it.
 // The fields are grouped by consumer: line 0 holds what the ray tracing stages and the MIS walks
 // read (position, the two area pdfs, object / flags, texture coordinates), line 1 the normals,
-// line 2 the rest of the shading frame and the throughput. A vertex is UPathVertex
+// line 2 the rest of the shading frame and the throughput (moving the geometric normal into line 0
+// and the specular flags into the subpath's count word was measured: the visibility kernel gained
+// 6 %, evaluation and shading lost more). A vertex is UPathVertex
 // (uengine/ubdptrenderer.h:9-24) minus the two 128-byte matrices and the shared_ptrs, which are
 // replaced by the object index and the lobe id.
 #pragma once
