@@ -624,11 +624,11 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         //           3 = wavefront with fused trace+shade bounce kernel + in-place dense / queued sparse pairs
         const uint32_t pl = c->opt.pipeline;
         if (pl == 0 || pl == 3) {
-            // wavefront pipelines: the count word of subpath `id` is the spare eighth double of its carry record
-            // (eye subpaths first, then the light subpaths), so trace and shade touch one line less per subpath
+            // wavefront pipelines: the count word of subpath `id` is the eighth double of its carry record's first
+            // line (eye subpaths first, then the light subpaths), so trace and shade touch one line less per subpath
             const uint32_t stride = kCarryDoubles * (uint32_t)(sizeof(double) / sizeof(uint32_t));
-            A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + (kCarryDoubles - 1));
-            A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + (kCarryDoubles - 1));
+            A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + kCarryCountSlot);
+            A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + kCarryCountSlot);
             A.E.count_stride = A.L.count_stride = stride;
         }
         const uint32_t D = c->wf_depth;

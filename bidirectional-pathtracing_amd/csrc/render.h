@@ -21,7 +21,7 @@ struct RenderArgs {
     unsigned long long pair_capacity;
     unsigned long long* pair_count;   // device counter, zeroed before every batch
     // wavefront subpath generation (wavefront.h); subpath id in [0, 2n)
-    double* carry;           // [2n][kCarryDoubles]: ray direction, BSDF value, pdf of the last scattering
+    double* carry;           // [2n][kCarryDoubles]: the ray in flight and what the next bounce needs of the last two vertices
     double* wf_hit;          // [2n][kHitDoubles]: d, u, v, (object | face << 32) of the closest hit found by k_wf_trace
     uint32_t* wf_hit_q;      // hit queue: id | region << 29, chunks padded to whole waves with 0xffffffff
     uint64_t* vis_pairs;     // connection pairs that passed the shadow ray
@@ -32,7 +32,8 @@ struct RenderArgs {
 
 constexpr uint32_t kMaxWfDepth = 30;  // most bounces that can run as wavefront launches before the tail loop takes over
 constexpr int kWfQStride = 16;        // counters per depth: [0] trace queue length, [1] hit queue length
-constexpr int kCarryDoubles = 8;      // one 64-byte line per subpath
+constexpr int kCarryDoubles = 16;     // two 64-byte lines per subpath
+constexpr int kCarryCountSlot = 7;    // the double of the first line that holds the subpath's count word
 constexpr int kHitDoubles = 4;        // half a line per subpath
 void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
 void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);

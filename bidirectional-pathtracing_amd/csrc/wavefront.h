@@ -20,27 +20,44 @@
 
 namespace ub {
 
-struct Carry {  // what a subpath keeps between two bounces besides its stored vertices
-    d3 dir;     // direction of the ray leaving the last vertex
-    d3 fs;      // BSDF value and pdf of the scattering at the last vertex
-    double p_psa;  // (light subpath before its first hit: dirT.y of the emission sample)
+// What a subpath keeps between two bounces: everything the next bounce needs of the vertices already
+// stored, so that subpath generation only ever WRITES vertex records. Two 64-byte lines; the ray
+// tracing stage reads the first one only (its eighth double is the subpath's count word).
+struct Carry {
+    d3 pos;          // last stored vertex = origin of the ray in flight
+    d3 dir;          // its direction
+    double p_psa;    // pdf of the scattering that chose dir (light subpath before its first hit: dirT.y of the emission sample)
+    d3 a;            // throughput the next vertex receives
+    d3 Ns;           // shading normal of the last stored vertex
+    double q;        // roulette survival probability the ray in flight already passed
+    double pending;  // area pdf the vertex BEFORE the last one receives if the ray in flight finds a
+                     // surface to continue from (the reference writes it only then, :379-395 / :568-584)
 };
 
 DEV void loadCarry(const RenderArgs& A, uint64_t id, Carry& c) {
     const double* p = A.carry + id * kCarryDoubles;
-    c.dir = mk3(p[0], p[1], p[2]);
-    c.fs = mk3(p[3], p[4], p[5]);
+    c.pos = mk3(p[0], p[1], p[2]);
+    c.dir = mk3(p[3], p[4], p[5]);
     c.p_psa = p[6];
+    c.a = mk3(p[8], p[9], p[10]);
+    c.Ns = mk3(p[11], p[12], p[13]);
+    c.q = p[14];
+    c.pending = p[15];
 }
-DEV d3 loadCarryDir(const RenderArgs& A, uint64_t id) {
+DEV void loadCarryRay(const RenderArgs& A, uint64_t id, Ray& r) {
     const double* p = A.carry + id * kCarryDoubles;
-    return mk3(p[0], p[1], p[2]);
+    r.o = mk3(p[0], p[1], p[2]);
+    r.d = mk3(p[3], p[4], p[5]);
 }
 DEV void storeCarry(const RenderArgs& A, uint64_t id, const Carry& c) {
     double* p = A.carry + id * kCarryDoubles;
-    p[0] = c.dir.x; p[1] = c.dir.y; p[2] = c.dir.z;
-    p[3] = c.fs.x; p[4] = c.fs.y; p[5] = c.fs.z;
+    p[0] = c.pos.x; p[1] = c.pos.y; p[2] = c.pos.z;
+    p[3] = c.dir.x; p[4] = c.dir.y; p[5] = c.dir.z;
     p[6] = c.p_psa;
+    p[8] = c.a.x; p[9] = c.a.y; p[10] = c.a.z;
+    p[11] = c.Ns.x; p[12] = c.Ns.y; p[13] = c.Ns.z;
+    p[14] = c.q;
+    p[15] = c.pending;
 }
 DEV void storeHit(const RenderArgs& A, uint64_t id, const Closest& h) {
     double* p = A.wf_hit + id * kHitDoubles;
@@ -78,68 +95,60 @@ DEV Rng pathRng(const RenderArgs& A, uint64_t i, bool light, uint64_t& pixel) {
     return r;
 }
 
-// One bounce of one subpath after its ray found `hit` with the lobe `lobe` already chosen:
-// the second half of one loop iteration of computeEyeSubpath / computeLightSubpath followed by the
-// first half of the next. Returns true when a vertex was pushed; `ray` and `cy` then describe the
-// next ray. n = subpath.size() on entry, updated on push.
+// One bounce of one subpath after the ray described by `cy` found `hit`, with the lobe `lobe` already
+// chosen: the second half of one loop iteration of computeEyeSubpath / computeLightSubpath followed
+// by the first half of the next. The tests of the next iteration that do not depend on what the next
+// ray hits (throughput and pdf positive, :346 / :537, and Russian roulette — the generator is
+// counter-based, so the draw does not depend on when it is made) are applied here already: a subpath
+// that would fail them is not traced again, and what the reference would compute from the last TWO
+// vertices after the next hit is computed now, while both are in registers, and carried in `cy`.
+// Returns true when a vertex was pushed and the subpath goes on; `cy` then describes the next ray.
+// n = subpath.size() on entry, updated on push.
 template <bool STATS, bool LIGHT>
-DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& rng, uint32_t& n, Ray& ray,
-                   const Closest& hit, int lobe, Carry& cy, Tally& ty) {
+DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& rng, uint32_t& n, const Closest& hit,
+                   int lobe, Carry& cy, Tally& ty) {
     const DScene& S = A.S;
     const PathStore& P = LIGHT ? A.L : A.E;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+    Ray ray;
+    ray.o = cy.pos; ray.d = cy.dir;
     Vertex nv;
     surfacePoint(S, ray, hit, nv.sp);
     nv.sp.lobe = lobe;
     nv.p_light_A = 0; nv.p_eye_A = 0; nv.specular = false;
+    const uint32_t meta = P.meta(i);
     Tail cur;
-    cur.pos = P.ld3(F_POS, n - 1, i);
-    cur.Ns = P.ld3(F_NS, n - 1, i);
-    cur.p_eye_A = P.ld(F_PE, n - 1, i);
-    cur.specular = P.specular(n - 1, i);
-    d3 cur_a = P.ld3(F_A, n - 1, i);
-    bool prev_specular = false;
+    cur.pos = cy.pos;
+    cur.Ns = cy.Ns;
+    cur.specular = !P.connectable(meta, n - 1, i);
+    nv.a = cy.a;
     if (n == 1) {
-        nv.a = cur_a;
         if (!LIGHT) nv.p_eye_A = 1.0 / S.image_plane_area;  // :265-267
         else {                                              // :463-472, hit still in object-local space
             double G = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
             nv.p_light_A = (1 / (2.0 * kPi * cy.p_psa)) * G;
         }
     } else {
-        d3 prev_pos = P.ld3(F_POS, n - 2, i), prev_Ns = P.ld3(F_NS, n - 2, i);
-        prev_specular = P.specular(n - 2, i);
-        double fs_sum = cy.fs.x + cy.fs.y + cy.fs.z;
-        if (!(cy.p_psa > 0) || !(fs_sum > 0)) return false;  // :346 / :537
-        double q;
-        if (n < S.min_depth) q = 1.0;
-        else {
-            q = fmin(1.0, (fs_sum / 3.0) / cy.p_psa);
-            if (rng(hitDim(n - 1, DIM_ROULETTE)) > q) return false;
-        }
+        P.st(LIGHT ? F_PE : F_PL, n - 2, i, cy.pending);
         if (cur.specular) {
-            nv.a = cur_a * cy.fs;
-            if (!LIGHT) { nv.p_eye_A = q * cy.p_psa; P.st(F_PL, n - 2, i, q * cy.p_psa); }
-            else        { nv.p_light_A = q * 1.0;    P.st(F_PE, n - 2, i, q * 1.0); }
+            if (!LIGHT) nv.p_eye_A = cy.q * cy.p_psa;
+            else        nv.p_light_A = cy.q * 1.0;
         } else {
-            d3 a = cy.fs / cy.p_psa;
             // G_next uses the new hit's OBJECT-LOCAL position and normal, as the reference does (:389-393, :578-582)
             double G_next = geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
-            nv.a = cur_a * a;
-            if (!LIGHT) {
-                double G_prev = geomAbs(cur.pos, cur.Ns, prev_pos, prev_Ns);
-                nv.p_eye_A = q * cy.p_psa * G_next;
-                P.st(F_PL, n - 2, i, q * cy.p_psa * G_prev);
-            } else {
-                double G_prev = geomAbs(prev_pos, prev_Ns, cur.pos, cur.Ns);
-                nv.p_light_A = q * cy.p_psa * G_next;
-                P.st(F_PE, n - 2, i, q * cy.p_psa * G_prev);
-            }
+            if (!LIGHT) nv.p_eye_A = cy.q * cy.p_psa * G_next;
+            else        nv.p_light_A = cy.q * cy.p_psa * G_next;
         }
     }
     const DObject& obj = S.objects[nv.sp.object];
+    const bool emits = !LIGHT && obj.is_emitter;  // s = 0 sample: the eye subpath ran into a light
+    bool prev_specular = false;
+    if (emits) {
+        cur.p_eye_A = P.ld(F_PE, n - 1, i);
+        prev_specular = n > 1 && !P.connectable(meta, n - 2, i);
+    }
     if (lobe == LOBE_NONE) {
-        if (!LIGHT) {  // :273-283
+        if (emits) {  // :273-283
             nv.sp.pos = transformPoint(obj.W, nv.sp.pos);
             nv.sp.Ns = transformVectorT(obj.invW, nv.sp.Ns);
             d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
@@ -158,16 +167,37 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
                      p_psa, fs, nv.specular))
         return false;
     finishVertex(obj, nv, dirT);
-    if (!LIGHT) {
+    if (emits) {
         d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
         if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
     }
     storeVertex(P, n, i, nv);
     n++;
-    P.setMeta(i, ((P.meta(i) & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n);
-    ray.o = nv.sp.pos;
-    ray.d = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
-    cy.dir = ray.d; cy.fs = fs; cy.p_psa = p_psa;
+    P.setMeta(i, ((meta & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n);
+    // the head of the next loop iteration (:346-356 / :537-547), n being the new size
+    double fs_sum = fs.x + fs.y + fs.z;
+    if (!(p_psa > 0) || !(fs_sum > 0)) return false;
+    double q;
+    if (n < S.min_depth) q = 1.0;
+    else {
+        q = fmin(1.0, (fs_sum / 3.0) / p_psa);
+        if (rng(hitDim(n - 1, DIM_ROULETTE)) > q) return false;
+    }
+    // throughput of the next vertex and the pdf its hit will hand back to vertex n - 2 (:358-395 / :549-584)
+    if (nv.specular) {
+        cy.a = nv.a * fs;
+        cy.pending = !LIGHT ? q * p_psa : q * 1.0;
+    } else {
+        d3 a = fs / p_psa;
+        cy.a = nv.a * a;
+        double G_prev = !LIGHT ? geomAbs(nv.sp.pos, nv.sp.Ns, cur.pos, cur.Ns) : geomAbs(cur.pos, cur.Ns, nv.sp.pos, nv.sp.Ns);
+        cy.pending = q * p_psa * G_prev;
+    }
+    cy.pos = nv.sp.pos;
+    cy.Ns = nv.sp.Ns;
+    cy.dir = transformVector(obj.W, float_tnb_mul(lTs, lNs, lBs, dirT));
+    cy.p_psa = p_psa;
+    cy.q = q;
     return true;
 }
 
@@ -186,7 +216,8 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
         decodePath(A, i, pass, pixel, px, py);
         Rng rng{pathKey(A.seed, pass, pixel), light ? (uint32_t)STREAM_LIGHT : (uint32_t)STREAM_EYE};
         Carry cy;
-        cy.fs = mk3(0, 0, 0); cy.p_psa = 0; cy.dir = mk3(0, 0, 0);
+        cy.pos = cy.dir = cy.a = cy.Ns = mk3(0, 0, 0);
+        cy.p_psa = 0; cy.q = 1.0; cy.pending = 0;
         if (!light) {
             uint32_t pixel_sample = (uint32_t)(pass % S.num_pixel_strata);
             uint32_t lens_sample = (uint32_t)(pass % S.num_lens_strata);
@@ -210,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             image_pointV = normalize(image_pointV);
             d3 focus_plane_pointV = image_pointV * (S.focus_plane_distance / image_pointV.z);
             cy.dir = transformVector(S.invV, focus_plane_pointV - lens_pointV);
+            cy.pos = lens.sp.pos; cy.Ns = lens.sp.Ns; cy.a = lens.a;
             live = true;
         } else if (S.num_emitters > 0) {
             double p = rng(DIM_EMITTER);
@@ -234,6 +266,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             d3 dirT = samplePosHemUniform(rng(DIM_EMIT_ANGLE), rng(DIM_EMIT_V));
             cy.dir = float_tnb_mul(ev.sp.Ts, ev.sp.Ns, ev.sp.Bs, dirT);
             cy.p_psa = dirT.y;
+            cy.pos = ev.sp.pos; cy.Ns = ev.sp.Ns; cy.a = ev.a;
             live = true;
         } else {
             A.L.setMeta(i, 0);
@@ -282,8 +315,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
             uint32_t n = P.cnt(i);
             if (n > 0) {
                 Ray ray;
-                ray.o = P.ld3(F_POS, n - 1, i);
-                ray.d = loadCarryDir(A, id);
+                loadCarryRay(A, id, ray);
                 hit = closestHit<STATS>(S, ray, st, ty);
                 if (hit.object >= 0) {
                     uint64_t pixel;
@@ -330,11 +362,8 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
             Rng rng = pathRng(A, i, light, pixel);
             Carry cy;
             loadCarry(A, sid, cy);
-            Ray ray;
-            ray.o = P.ld3(F_POS, n - 1, i);
-            ray.d = cy.dir;
-            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, h2, lobe, cy, ty)
-                         : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, h2, lobe, cy, ty);
+            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, h2, lobe, cy, ty)
+                         : shadeStep<STATS, false>(A, i, pixel, rng, n, h2, lobe, cy, ty);
             if (cont) storeCarry(A, sid, cy);
         }
         // (4) survivors -> next queue, one global atomic per chunk
@@ -381,16 +410,15 @@ __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A, uint32_t depth
         Rng rng = pathRng(A, i, light, pixel);
         Carry cy;
         loadCarry(A, id, cy);
-        Ray ray;
-        ray.o = P.ld3(F_POS, n - 1, i);
-        ray.d = cy.dir;
         for (;;) {
+            Ray ray;
+            ray.o = cy.pos; ray.d = cy.dir;
             Closest hit = closestHit<STATS>(S, ray, st, ty);
             if (hit.object < 0) break;
             int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
             if (light && lobe == LOBE_NONE) break;
-            bool cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty)
-                              : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty);
+            bool cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
+                              : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
             if (!cont) break;
         }
     }

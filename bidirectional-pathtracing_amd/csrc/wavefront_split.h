@@ -73,8 +73,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
             uint32_t n = P.cnt(i);
             if (n > 0) {
                 Ray ray;
-                ray.o = P.ld3(F_POS, n - 1, i);
-                ray.d = loadCarryDir(A, id);
+                loadCarryRay(A, id, ray);
                 Closest hit = closestHit<STATS>(S, ray, st, ty);
                 if (hit.object >= 0) {
                     uint64_t pixel;
@@ -147,13 +146,10 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t dept
                 Rng rng = pathRng(A, i, light, pixel);
                 Carry cy;
                 loadCarry(A, id, cy);
-                Ray ray;
-                ray.o = P.ld3(F_POS, n - 1, i);
-                ray.d = cy.dir;
                 Closest hit;
                 loadHit(A, id, hit);
-                cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty)
-                             : shadeStep<STATS, false>(A, i, pixel, rng, n, ray, hit, lobe, cy, ty);
+                cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
+                             : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
                 if (cont) storeCarry(A, id, cy);
             }
         }

@@ -194,9 +194,15 @@ def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipe
     # work counters: the backend traced (almost) exactly the paths the oracle traced
     s = ctx.stats()
     assert s["pixel_samples"] == cn["pixel_samples"] == w * h * passes
-    for k, tol in (("closest_hit_rays", 2e-3), ("eye_vertices", 2e-3), ("light_vertices", 2e-3),
-                   ("connections", 5e-3), ("splats", 5e-3)):
+    for k, tol in (("eye_vertices", 2e-3), ("light_vertices", 2e-3), ("connections", 5e-3), ("splats", 5e-3)):
         assert abs(s[k] - cn[k]) <= tol * cn[k] + 2, (k, s[k], cn[k])
+    # the wavefront pipelines decide Russian roulette before they trace the next ray (same draw, same
+    # outcome), so they trace fewer closest-hit rays than the reference order does, never more
+    k = "closest_hit_rays"
+    if pipeline in (0, 3):
+        assert 0.8 * cn[k] < s[k] <= cn[k] * (1 + 2e-3) + 2, (k, s[k], cn[k])
+    else:
+        assert abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2, (k, s[k], cn[k])
     ctx.close()
 
 
