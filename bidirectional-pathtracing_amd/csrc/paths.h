@@ -5,10 +5,12 @@
 // sparsely used, and every 8-byte access of a lone survivor would still fetch a whole 64-byte line
 // from HBM; with one record per vertex every fetched line is data of the vertex that asked for it.
 // The fields are grouped by consumer: line 0 holds what the ray tracing stages and the MIS walks
-// read (position, the two area pdfs, object / flags, texture coordinates), line 1 the normals,
-// line 2 the rest of the shading frame and the throughput (moving the geometric normal into line 0
-// and the specular flags into the subpath's count word was measured: the visibility kernel gained
-// 6 %, evaluation and shading lost more). A vertex is UPathVertex
+// read (position, the two area pdfs, object / flags), line 1 the normals, line 2 the rest of the
+// shading frame and the throughput (moving the geometric normal into line 0 and the specular flags
+// into the subpath's count word was measured: the visibility kernel gained 6 %, evaluation lost
+// more). Instead of its texture coordinates a vertex stores the texture's colour there, which
+// shading has looked up anyway: a connection then evaluates the BSDF without following
+// object -> texture -> texel. A vertex is UPathVertex
 // (uengine/ubdptrenderer.h:9-24) minus the two 128-byte matrices and the shared_ptrs, which are
 // replaced by the object index and the lobe id.
 #pragma once
@@ -17,7 +19,7 @@
 
 namespace ub {
 
-enum { F_POS = 0, F_PL = 3, F_PE = 4, F_U = 5, F_V = 6, F_OBJFLAGS = 7, F_NG = 8, F_NS = 11, F_TS = 14, F_BS = 17, F_A = 20,
+enum { F_POS = 0, F_PL = 3, F_PE = 4, F_OBJFLAGS = 5, F_TEX = 6, F_NG = 9, F_NS = 12, F_TS = 15, F_BS = 18, F_A = 21,
        kVertexDoubles = 24 };
 
 // The count word of a subpath: bits 0..7 = vertices stored, bit 8 + k = vertex k is specular
@@ -68,6 +70,7 @@ struct PathStore {
 struct Vertex {
     SurfacePoint sp;
     d3 a;
+    d3 tex;  // textureSample at (sp.tex_u, sp.tex_v); unused for lens and emitter vertices
     bool specular;
     double p_light_A, p_eye_A;
 };
@@ -76,7 +79,7 @@ DEV void storeVertex(const PathStore& P, uint32_t slot, uint64_t i, const Vertex
     P.st3(F_POS, slot, i, x.sp.pos); P.st3(F_NG, slot, i, x.sp.Ng); P.st3(F_NS, slot, i, x.sp.Ns);
     P.st3(F_TS, slot, i, x.sp.Ts);   P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
     P.st(F_PL, slot, i, x.p_light_A); P.st(F_PE, slot, i, x.p_eye_A);
-    P.st(F_U, slot, i, x.sp.tex_u);   P.st(F_V, slot, i, x.sp.tex_v);
+    P.st3(F_TEX, slot, i, x.tex);
     P.setObjFlags(slot, i, x.sp.object, ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0));
 }
 
@@ -150,8 +153,8 @@ DEV double geomAbs(d3 from, d3 n_from, d3 to, d3 n_to) {
 
 // A stored vertex as the connection code needs it.
 struct ConnVertex {
-    d3 pos, Ng, Ns, Ts, Bs, a;
-    double p_light_A, p_eye_A, tex_u, tex_v;
+    d3 pos, Ng, Ns, Ts, Bs, a, tex;
+    double p_light_A, p_eye_A;
     int32_t object;
     int lobe;
     bool specular;
@@ -160,7 +163,7 @@ DEV void loadConn(const PathStore& P, uint32_t slot, uint64_t i, ConnVertex& c) 
     c.pos = P.ld3(F_POS, slot, i); c.Ng = P.ld3(F_NG, slot, i); c.Ns = P.ld3(F_NS, slot, i);
     c.Ts = P.ld3(F_TS, slot, i);   c.Bs = P.ld3(F_BS, slot, i); c.a = P.ld3(F_A, slot, i);
     c.p_light_A = P.ld(F_PL, slot, i); c.p_eye_A = P.ld(F_PE, slot, i);
-    c.tex_u = P.ld(F_U, slot, i); c.tex_v = P.ld(F_V, slot, i);
+    c.tex = P.ld3(F_TEX, slot, i);
     c.object = P.obj(slot, i);
     int f = P.flg(slot, i);
     c.lobe = (f & 0xff) - 1;
@@ -204,6 +207,28 @@ DEV bool lambertSameSide(const ConnVertex& v, d3 a, d3 b) {
 template <class SL, class SE>
 DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, const ConnVertex& vl,
                         const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, d3& c, double& w) {
+    // The first kAhead steps of the two MIS walks below depend on stored pdfs only: their loads are
+    // issued here, together with the loads of the two end vertices, instead of after the
+    // connection's arithmetic (step k of the eye walk is vertex t-2-k, of the light walk s-2-k;
+    // vertex 0 of either subpath — lens, emitter — is never specular).
+    constexpr int kAhead = 3;
+    double rE[kAhead], rL[kAhead];
+    uint32_t specE = 0, specL = 0;
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) {
+        int v = (int)t - 2 - k;
+        rE[k] = 0;
+        if (v > 0) {
+            rE[k] = E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
+            specE |= (E.specular(v, i) ? 1u : 0u) << k;
+        }
+        v = (int)s - 2 - k;
+        rL[k] = 0;
+        if (v >= 0) {
+            rL[k] = L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
+            specL |= (L.specular(v, i) ? 1u : 0u) << k;
+        }
+    }
     d3 ce = vl.pos - ve.pos;
     double ce_length2 = dot(ce, ce);
     ce = ce / sqrt(ce_length2);
@@ -218,7 +243,7 @@ DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, c
         fs1 = mk3(1, 1, 1) * (1.0 / (2.0 * kPi * d2));
     else {
         if (!lambertSameSide(vl, lprev - vl.pos, ve.pos - vl.pos)) return false;
-        fs1 = (1.0 / kPi) * textureSample(S, S.objects[vl.object].texture, vl.tex_u, vl.tex_v);
+        fs1 = (1.0 / kPi) * vl.tex;
         if (fs1.x + fs1.y + fs1.z <= 0) return false;
     }
     if (t == 1) {
@@ -229,7 +254,7 @@ DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, c
         fs2 = mk3(1, 1, 1) * ((1.0 / (S.image_plane_area)) / G_image_plane);
     } else {
         if (!lambertSameSide(ve, vl.pos - ve.pos, eprev - ve.pos)) return false;
-        fs2 = (1.0 / kPi) * textureSample(S, S.objects[ve.object].texture, ve.tex_u, ve.tex_v);
+        fs2 = (1.0 / kPi) * ve.tex;
         if (fs2.x + fs2.y + fs2.z <= 0) return false;
     }
     c = fs1 * fs2 * G;
@@ -241,29 +266,50 @@ DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, c
         ratio = (s == 1) ? (1.0 / (2.0 * kPi * d2)) : (1.0 / kPi);
         ratio *= G;
         ratio = ratio / ve.p_eye_A;
-        if (!E.specular(t - 2, i)) w += ratio * ratio;
+        if (!(specE & 1u)) w += ratio * ratio;
     }
-    if (t > 2)
-        for (int v = (int)t - 2; v > 0; v--) {
-            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
-            if (E.specular(v, i)) continue;
-            if (E.specular(v - 1, i)) continue;
+    if (t > 2) {
+        int v = (int)t - 2;
+#pragma unroll
+        for (int k = 0; k < kAhead; k++, v--) {
+            if (v < 1) break;
+            ratio *= rE[k];
+            if ((specE >> k) & 1u) continue;
+            if (k + 1 < kAhead ? ((specE >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && E.specular(v - 1, i))) continue;
             w += ratio * ratio;
         }
+        for (; v > 0; v--) {
+            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
+            if (E.specular(v, i)) continue;
+            if (v - 1 > 0 && E.specular(v - 1, i)) continue;
+            w += ratio * ratio;
+        }
+    }
     double p_eye_A = (t == 1) ? (1.0 / S.image_plane_area) : ((1.0 / kPi) * G);
     ratio = (p_eye_A / vl.p_light_A);
     if (s > 1) {
-        if (!L.specular(s - 2, i)) w += ratio * ratio;
+        if (!(specL & 1u)) w += ratio * ratio;
     } else
         w += ratio * ratio;
-    if (s > 1)
-        for (int v = (int)s - 2; v >= 0; v--) {
+    if (s > 1) {
+        int v = (int)s - 2;
+#pragma unroll
+        for (int k = 0; k < kAhead; k++, v--) {
+            if (v < 0) break;
+            ratio *= rL[k];
+            if ((specL >> k) & 1u) continue;
+            if (v > 0)
+                if (k + 1 < kAhead ? ((specL >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && L.specular(v - 1, i))) continue;
+            w += ratio * ratio;
+        }
+        for (; v >= 0; v--) {
             ratio *= L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
             if (L.specular(v, i)) continue;
-            if (v > 0)
+            if (v > 1)
                 if (L.specular(v - 1, i)) continue;
             w += ratio * ratio;
         }
+    }
     w = 1.0 / w;
     return true;
 }
@@ -286,8 +332,7 @@ DEV bool connectionFactorTail(const DScene& S, const ConnVertex& vl, const ConnV
         fs1 = mk3(1, 1, 1) * (1.0 / (2.0 * kPi * d2));
     else {
         m3 TNB = mk_m3(vl.Ts, vl.Ns, vl.Bs);
-        fs1 = bsdfEval(vl.lobe, S.objects[vl.object].mat_a, textureSample(S, S.objects[vl.object].texture, vl.tex_u, vl.tex_v),
-                       frameOf(vl), normalize(rowmul(lprev - vl.pos, TNB)), normalize(rowmul(ve.pos - vl.pos, TNB)));
+        fs1 = bsdfEval(vl.lobe, S.objects[vl.object].mat_a, vl.tex, frameOf(vl), normalize(rowmul(lprev - vl.pos, TNB)), normalize(rowmul(ve.pos - vl.pos, TNB)));
         if (fs1.x + fs1.y + fs1.z <= 0) return false;
     }
     if (t == 1) {
@@ -298,8 +343,7 @@ DEV bool connectionFactorTail(const DScene& S, const ConnVertex& vl, const ConnV
         fs2 = mk3(1, 1, 1) * ((1.0 / (S.image_plane_area)) / G_image_plane);
     } else {
         m3 TNB = mk_m3(ve.Ts, ve.Ns, ve.Bs);
-        fs2 = bsdfEval(ve.lobe, S.objects[ve.object].mat_a, textureSample(S, S.objects[ve.object].texture, ve.tex_u, ve.tex_v),
-                       frameOf(ve), normalize(rowmul(vl.pos - ve.pos, TNB)), normalize(rowmul(eprev - ve.pos, TNB)));
+        fs2 = bsdfEval(ve.lobe, S.objects[ve.object].mat_a, ve.tex, frameOf(ve), normalize(rowmul(vl.pos - ve.pos, TNB)), normalize(rowmul(eprev - ve.pos, TNB)));
         if (fs2.x + fs2.y + fs2.z <= 0) return false;
     }
     c = fs1 * fs2 * G;

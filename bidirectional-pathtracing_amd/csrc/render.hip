@@ -115,6 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
 
     Vertex lens;
     lens.a = mk3(1.0, 1.0, 1.0);  // m_W
+    lens.tex = mk3(0, 0, 0);
     lens.sp.pos = mul_xyz(S.invV, lens_pointV, 1.0);
     lens.sp.Ns = lens.sp.Ng = transformVector(S.invV, mk3(0, 0, 1));
     lens.sp.Ts = transformVector(S.invV, mk3(1, 0, 0));
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
         Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
         d3 w = transformVector(obj.invW, -ray.d);
         d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+        nv.tex = tex;
         double p_psa;
         d3 fs, dirT;
         if (!bsdfScatter(nv.sp.lobe, obj.mat_a, tex, fr, w, rng(hitDim(h, DIM_SCATTER_1)), rng(hitDim(h, DIM_SCATTER_2)),
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
         emitterRandomPoint(S, em, rng, ev.sp.pos, ev.sp.Ng, ev.sp.Ns, ev.sp.Ts, ev.sp.Bs);
         ev.sp.tex_u = 0; ev.sp.tex_v = 0; ev.sp.object = ei; ev.sp.lobe = LOBE_NONE; ev.sp.face = 0;
         ev.a = em.power;
+        ev.tex = mk3(0, 0, 0);
         ev.p_light_A = em.prob * (1.0 / em.area);
         ev.p_eye_A = 0;  // indeterminate in the reference (:433), zero here
         ev.specular = false;
@@ -322,6 +325,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
             Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
             d3 w = transformVector(obj.invW, -ray.d);
             d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+            nv.tex = tex;
             double p_psa;
             d3 fs, dT;
             if (!bsdfScatter(nv.sp.lobe, obj.mat_a, tex, fr, w, rng(hitDim(h, DIM_SCATTER_1)),

@@ -161,6 +161,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     Frame fr; fr.Ng = nv.sp.Ng; fr.Ns = nv.sp.Ns; fr.Ts = nv.sp.Ts; fr.Bs = nv.sp.Bs;
     d3 w = transformVector(obj.invW, -ray.d);
     d3 tex = textureSample(S, obj.texture, nv.sp.tex_u, nv.sp.tex_v);
+    nv.tex = tex;
     double p_psa;
     d3 fs, dirT;
     if (!bsdfScatter(lobe, obj.mat_a, tex, fr, w, rng(hitDim(n, DIM_SCATTER_1)), rng(hitDim(n, DIM_SCATTER_2)), dirT,
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             d3 lens_pointV = mk3(S.lens_radius * disk.x, S.lens_radius * disk.y, 0);
             Vertex lens;
             lens.a = mk3(1.0, 1.0, 1.0);
+            lens.tex = mk3(0, 0, 0);
             lens.sp.pos = mul_xyz(S.invV, lens_pointV, 1.0);
             lens.sp.Ns = lens.sp.Ng = transformVector(S.invV, mk3(0, 0, 1));
             lens.sp.Ts = transformVector(S.invV, mk3(1, 0, 0));
@@ -258,6 +260,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             emitterRandomPoint(S, em, rng, ev.sp.pos, ev.sp.Ng, ev.sp.Ns, ev.sp.Ts, ev.sp.Bs);
             ev.sp.tex_u = 0; ev.sp.tex_v = 0; ev.sp.object = ei; ev.sp.lobe = LOBE_NONE; ev.sp.face = 0;
             ev.a = em.power;
+            ev.tex = mk3(0, 0, 0);
             ev.p_light_A = em.prob * (1.0 / em.area);
             ev.p_eye_A = 0;
             ev.specular = false;
