@@ -199,36 +199,42 @@ DEV bool lambertSameSide(const ConnVertex& v, d3 a, d3 b) {
     return !(dot(v.Ng, aL) * dot(v.Ng, bL) <= 0);
 }
 
+// The first kWalkAhead steps of the two MIS walks of a connection depend on stored pdfs only (step
+// k of the eye walk is vertex t-2-k, of the light walk vertex s-2-k). They are loaded WITHOUT
+// branches (a step that does not exist reads vertex 0 instead and is never used), so that the
+// caller can issue them together with the loads of the two end vertices: one round trip to memory
+// instead of one per step after the connection's arithmetic. Vertex 0 of either subpath (lens,
+// emitter) is never specular.
+constexpr int kWalkAhead = 3;
+struct WalkAhead {
+    double plE[kWalkAhead], peE[kWalkAhead], plL[kWalkAhead], peL[kWalkAhead];
+    uint32_t specE, specL;  // bit k: the vertex of step k is specular
+};
+DEV void loadWalkAhead(const PathStore& L, const PathStore& E, uint64_t i, uint32_t s, uint32_t t, WalkAhead& a) {
+    a.specE = a.specL = 0;
+#pragma unroll
+    for (int k = 0; k < kWalkAhead; k++) {
+        int v = (int)t - 2 - k;
+        uint32_t vc = v > 0 ? (uint32_t)v : 0u;
+        a.plE[k] = E.ld(F_PL, vc, i);
+        a.peE[k] = E.ld(F_PE, vc, i);
+        a.specE |= ((v > 0) & ((E.flg(vc, i) >> 8) & 1)) ? (1u << k) : 0u;
+        v = (int)s - 2 - k;
+        vc = v > 0 ? (uint32_t)v : 0u;
+        a.plL[k] = L.ld(F_PL, vc, i);
+        a.peL[k] = L.ld(F_PE, vc, i);
+        a.specL |= ((v > 0) & ((L.flg(vc, i) >> 8) & 1)) ? (1u << k) : 0u;
+    }
+}
+
 // Lambertian-only form of connectionFactorTail + misWeight below: a connected vertex is never
 // specular (ubdptrenderer.cpp:604), and every non-specular surface vertex carries the Lambertian
 // lobe, whose value (tex/pi) and pdf (1/pi) are constants once the same-side tests pass.
 // Returns false when the connection contributes nothing; otherwise c (connection factor) and w (MIS weight).
-// SL / SE: anything with ld(field, slot, i) and specular(slot, i) — the HBM PathStore or an LDS tile.
-template <class SL, class SE>
-DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, const ConnVertex& vl,
-                        const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, d3& c, double& w) {
-    // The first kAhead steps of the two MIS walks below depend on stored pdfs only: their loads are
-    // issued here, together with the loads of the two end vertices, instead of after the
-    // connection's arithmetic (step k of the eye walk is vertex t-2-k, of the light walk s-2-k;
-    // vertex 0 of either subpath — lens, emitter — is never specular).
-    constexpr int kAhead = 3;
-    double rE[kAhead], rL[kAhead];
-    uint32_t specE = 0, specL = 0;
-#pragma unroll
-    for (int k = 0; k < kAhead; k++) {
-        int v = (int)t - 2 - k;
-        rE[k] = 0;
-        if (v > 0) {
-            rE[k] = E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
-            specE |= (E.specular(v, i) ? 1u : 0u) << k;
-        }
-        v = (int)s - 2 - k;
-        rL[k] = 0;
-        if (v >= 0) {
-            rL[k] = L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
-            specL |= (L.specular(v, i) ? 1u : 0u) << k;
-        }
-    }
+DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+                        const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, const WalkAhead& wa, d3& c,
+                        double& w) {
+    const uint32_t specE = wa.specE, specL = wa.specL;
     d3 ce = vl.pos - ve.pos;
     double ce_length2 = dot(ce, ce);
     ce = ce / sqrt(ce_length2);
@@ -271,11 +277,11 @@ DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, c
     if (t > 2) {
         int v = (int)t - 2;
 #pragma unroll
-        for (int k = 0; k < kAhead; k++, v--) {
+        for (int k = 0; k < kWalkAhead; k++, v--) {
             if (v < 1) break;
-            ratio *= rE[k];
+            ratio *= wa.plE[k] / wa.peE[k];
             if ((specE >> k) & 1u) continue;
-            if (k + 1 < kAhead ? ((specE >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && E.specular(v - 1, i))) continue;
+            if (k + 1 < kWalkAhead ? ((specE >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && E.specular(v - 1, i))) continue;
             w += ratio * ratio;
         }
         for (; v > 0; v--) {
@@ -294,12 +300,12 @@ DEV bool connectLambert(const DScene& S, const SL& L, const SE& E, uint64_t i, c
     if (s > 1) {
         int v = (int)s - 2;
 #pragma unroll
-        for (int k = 0; k < kAhead; k++, v--) {
+        for (int k = 0; k < kWalkAhead; k++, v--) {
             if (v < 0) break;
-            ratio *= rL[k];
+            ratio *= wa.peL[k] / wa.plL[k];
             if ((specL >> k) & 1u) continue;
             if (v > 0)
-                if (k + 1 < kAhead ? ((specL >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && L.specular(v - 1, i))) continue;
+                if (k + 1 < kWalkAhead ? ((specL >> (k + 1)) & 1u) != 0 : (v - 1 > 0 && L.specular(v - 1, i))) continue;
             w += ratio * ratio;
         }
         for (; v >= 0; v--) {

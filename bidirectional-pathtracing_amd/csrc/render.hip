@@ -479,19 +479,23 @@ DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
     const PathStore& E = A.E;
     const PathStore& L = A.L;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
+    // every load whose address depends on (i, s, t) only is issued here, before the first use of any of them
+    // (the positions before the end vertices exist only for s, t > 1 and are only used then; slot 0 is read otherwise)
     ConnVertex vl, ve;
     loadConn(L, s - 1, i, vl);
     loadConn(E, t - 1, i, ve);
+    d3 lprev = L.ld3(F_POS, s > 1 ? s - 2 : 0, i);
+    d3 eprev = E.ld3(F_POS, t > 1 ? t - 2 : 0, i);
+    WalkAhead wa;
+    loadWalkAhead(L, E, i, s, t, wa);
     uint32_t tx = 0, tyy = 0;
     if (t == 1) {
         if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) return false;
     }
-    d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
-    d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
     d3 c;
     double w;
     if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
-        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, c, w)) return false;
+        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, wa, c, w)) return false;
     } else {
         if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return false;
         w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
@@ -529,10 +533,12 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     loadConn(E, t - 1, i, ve);
     d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
     d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
+    WalkAhead wa;
+    loadWalkAhead(L, E, i, s, t, wa);
     d3 c;
     double w;
     if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
-        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, c, w)) return;
+        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, wa, c, w)) return;
     } else {
         if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return;
         w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
