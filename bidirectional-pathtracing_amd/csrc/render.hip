@@ -882,8 +882,14 @@ void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool st
     else hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_wf_shade<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    else hipLaunchKernelGGL(k_wf_shade<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    const bool lds = A.S.num_objects <= kLdsObjects;
+    if (stats) {
+        if (lds) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
+        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    } else {
+        if (lds) hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
+        else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    }
 }
 void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_visible<true>, dim3(blocks), dim3(kBlock), 0, s, A);

@@ -116,10 +116,25 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
 }
 
 // ---- shade ------------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A, uint32_t depth) {
+// OBJ_LDS: the object table (transforms, material, emitter data: 480 bytes per object) is copied to
+// LDS by every workgroup first. Shading reads several parts of its object's record one after the
+// other; from LDS these dependent reads cost tens of cycles instead of a trip to L2 each.
+constexpr uint32_t kLdsObjects = 64;
+template <bool STATS, bool OBJ_LDS>
+__global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A0, uint32_t depth) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
+    __shared__ DObject s_objects[OBJ_LDS ? kLdsObjects : 1];
+    RenderArgs A = A0;
+    if (OBJ_LDS) {
+        static_assert(sizeof(DObject) % 16 == 0, "DObject is copied in 16-byte words");
+        const uint4* src = reinterpret_cast<const uint4*>(A0.S.objects);
+        uint4* dst = reinterpret_cast<uint4*>(s_objects);
+        const uint32_t words = A0.S.num_objects * (uint32_t)(sizeof(DObject) / 16);
+        for (uint32_t w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
+        __syncthreads();
+        A.S.objects = s_objects;
+    }
     const uint64_t N = A.E.n;
     const uint64_t n2 = 2 * N;
     const uint32_t tid = threadIdx.x;
