@@ -877,23 +877,26 @@ void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool sta
     if (stats) hipLaunchKernelGGL(k_connect_hybrid<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A, dense_threshold);
     else hipLaunchKernelGGL(k_connect_hybrid<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A, dense_threshold);
 }
+// picks the instantiation (counting or not, object table in LDS or not) of a kernel template K<bool, uint32_t>
+#define UBDPT_LAUNCH_LDS(K, CAP, ...)                                                                          \
+    do {                                                                                                       \
+        const bool lds_ = A.S.num_objects <= (CAP);                                                            \
+        if (stats) {                                                                                           \
+            if (lds_) hipLaunchKernelGGL((K<true, (CAP)>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);     \
+            else hipLaunchKernelGGL((K<true, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);             \
+        } else {                                                                                               \
+            if (lds_) hipLaunchKernelGGL((K<false, (CAP)>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);    \
+            else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
+        }                                                                                                      \
+    } while (0)
 void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_wf_trace<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    else hipLaunchKernelGGL(k_wf_trace<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    UBDPT_LAUNCH_LDS(k_wf_trace, kLdsObjectsTrace, A, depth);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    const bool lds = A.S.num_objects <= kLdsObjects;
-    if (stats) {
-        if (lds) hipLaunchKernelGGL((k_wf_shade<true, true>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
-        else hipLaunchKernelGGL((k_wf_shade<true, false>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    } else {
-        if (lds) hipLaunchKernelGGL((k_wf_shade<false, true>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
-        else hipLaunchKernelGGL((k_wf_shade<false, false>), dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    }
+    UBDPT_LAUNCH_LDS(k_wf_shade, kLdsObjectsShade, A, depth);
 }
 void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_pair_visible<true>, dim3(blocks), dim3(kBlock), 0, s, A);
-    else hipLaunchKernelGGL(k_pair_visible<false>, dim3(blocks), dim3(kBlock), 0, s, A);
+    UBDPT_LAUNCH_LDS(k_pair_visible, kLdsObjectsTrace, A);
 }
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);

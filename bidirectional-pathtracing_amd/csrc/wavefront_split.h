@@ -43,12 +43,32 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
     return pos;
 }
 
+// The object table (transforms, material, emitter data: 480 bytes per object) of a scene with few
+// objects is copied to LDS by every workgroup of a kernel instantiated with LDS_OBJECTS > 0. The
+// kernels read parts of a hit's object record at several points, each read depending on the one
+// before; from LDS such a read costs tens of cycles instead of a trip to L2. Every thread of the
+// workgroup must call this; the returned pointer replaces DScene::objects.
+constexpr uint32_t kLdsObjectsShade = 64;  // shading kernels hold 2 workgroups per CU
+constexpr uint32_t kLdsObjectsTrace = 32;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
+DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
+    static_assert(sizeof(DObject) % 16 == 0, "DObject is copied in 16-byte words");
+    const uint4* src = reinterpret_cast<const uint4*>(S.objects);
+    uint4* dst = reinterpret_cast<uint4*>(lds);
+    const uint32_t words = S.num_objects * (uint32_t)(sizeof(DObject) / 16);
+    for (uint32_t w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
+    __syncthreads();
+    return lds;
+}
+
 // ---- trace ------------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A, uint32_t depth) {
+template <bool STATS, uint32_t LDS_OBJECTS>
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
     __shared__ uint32_t s_base;
+    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
+    RenderArgs A = A0;
+    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
     const DScene& S = A.S;
     const uint64_t N = A.E.n;
     const uint64_t n2 = 2 * N;
@@ -116,25 +136,13 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
 }
 
 // ---- shade ------------------------------------------------------------------------------------------------
-// OBJ_LDS: the object table (transforms, material, emitter data: 480 bytes per object) is copied to
-// LDS by every workgroup first. Shading reads several parts of its object's record one after the
-// other; from LDS these dependent reads cost tens of cycles instead of a trip to L2 each.
-constexpr uint32_t kLdsObjects = 64;
-template <bool STATS, bool OBJ_LDS>
+template <bool STATS, uint32_t LDS_OBJECTS>
 __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A0, uint32_t depth) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
-    __shared__ DObject s_objects[OBJ_LDS ? kLdsObjects : 1];
+    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
     RenderArgs A = A0;
-    if (OBJ_LDS) {
-        static_assert(sizeof(DObject) % 16 == 0, "DObject is copied in 16-byte words");
-        const uint4* src = reinterpret_cast<const uint4*>(A0.S.objects);
-        uint4* dst = reinterpret_cast<uint4*>(s_objects);
-        const uint32_t words = A0.S.num_objects * (uint32_t)(sizeof(DObject) / 16);
-        for (uint32_t w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
-        __syncthreads();
-        A.S.objects = s_objects;
-    }
+    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
     const uint64_t N = A.E.n;
     const uint64_t n2 = 2 * N;
     const uint32_t tid = threadIdx.x;
@@ -175,11 +183,14 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A0, uint32_t dep
 }
 
 // ---- connections: visibility, then evaluation -----------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A) {
+template <bool STATS, uint32_t LDS_OBJECTS>
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A0) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
+    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
+    RenderArgs A = A0;
+    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
