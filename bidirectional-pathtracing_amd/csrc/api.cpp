@@ -381,6 +381,7 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
     S.nodes = c->d_nodes; S.prims = c->d_prims;
     S.num_objects = sd->num_objects; S.num_emitters = (uint32_t)emitters.size(); S.num_prims = (uint32_t)prims.size();
     S.accel = c->opt.accel; S.num_faces = sd->num_faces;
+    S.node_stride = (uint32_t)sizeof(BvhNode); S.pad0 = 0;
 
     // uengine/ucamera.cpp:3-14,67-70 and uengine/ubdptrenderer.cpp:7-33
     const ubdpt_camera& cam = sd->camera;

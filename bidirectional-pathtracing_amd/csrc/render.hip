@@ -889,14 +889,29 @@ void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool sta
             else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
         }                                                                                                      \
     } while (0)
+// the same for the ray tracing kernels K<bool, int>: how much of the scene fits into LDS
+#define UBDPT_LAUNCH_TRACE(K, ...)                                                                             \
+    do {                                                                                                       \
+        const bool obj_ = A.S.num_objects <= kLdsObjectsTrace;                                                 \
+        const bool tree_ = obj_ && A.S.accel == 0 && A.S.nodes && A.S.num_prims <= kLdsTreePrims;              \
+        if (stats) {                                                                                           \
+            if (tree_) hipLaunchKernelGGL((K<true, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);        \
+            else if (obj_) hipLaunchKernelGGL((K<true, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);    \
+            else hipLaunchKernelGGL((K<true, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);              \
+        } else {                                                                                               \
+            if (tree_) hipLaunchKernelGGL((K<false, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);       \
+            else if (obj_) hipLaunchKernelGGL((K<false, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);   \
+            else hipLaunchKernelGGL((K<false, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);             \
+        }                                                                                                      \
+    } while (0)
 void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_LDS(k_wf_trace, kLdsObjectsTrace, A, depth);
+    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
     UBDPT_LAUNCH_LDS(k_wf_shade, kLdsObjectsShade, A, depth);
 }
 void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_LDS(k_pair_visible, kLdsObjectsTrace, A);
+    UBDPT_LAUNCH_TRACE(k_pair_visible, A);
 }
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);

@@ -79,6 +79,8 @@ struct DScene {
     const BvhNode* nodes;
     const Prim* prims;
     uint32_t num_objects, num_emitters, num_prims, accel;
+    uint32_t node_stride;  // bytes between two tree nodes: sizeof(BvhNode) in HBM, padded in an LDS copy
+    uint32_t pad0;
     uint64_t num_faces;
 
     // UBDPTRenderer members (uengine/ubdptrenderer.h:54-79)

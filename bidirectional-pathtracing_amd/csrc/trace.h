@@ -205,7 +205,8 @@ DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
 }
 DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
                     TraceCounters* tc) {
-    const BvhNode nd = S.nodes[node];
+    const BvhNode nd =
+        *reinterpret_cast<const BvhNode*>(reinterpret_cast<const char*>(S.nodes) + (size_t)node * S.node_stride);
     if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
     const float inf = __builtin_inff();
     float t0, t1, t2, t3;

@@ -60,15 +60,48 @@ DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
     return lds;
 }
 
+// A scene of a few dozen primitives fits into LDS whole: tree nodes and primitives as well. A ray
+// then walks the tree without leaving the CU (traversal is a chain of dependent fetches, each of
+// which otherwise pays the latency of L2). Every thread of the workgroup must call this.
+constexpr uint32_t kLdsTreePrims = 48;
+// In LDS a node occupies 144 bytes: with the 128-byte stride of the HBM layout the lanes of a wave
+// that read the same field of different nodes would all hit the same few banks.
+struct __attribute__((aligned(16))) LdsNode {
+    BvhNode n;
+    uint32_t pad[4];
+};
+DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
+    static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
+    constexpr uint32_t kNodeWords = sizeof(BvhNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
+    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : S.num_prims;  // nodes of the binary tree the four-wide one is carved from
+    const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
+    uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
+    for (uint32_t w = threadIdx.x; w < n_nodes * kNodeWords; w += kBlock)
+        dst[(w / kNodeWords) * kLdsNodeWords + (w % kNodeWords)] = src[w];
+    src = reinterpret_cast<const uint4*>(S.prims);
+    dst = reinterpret_cast<uint4*>(lds_prims);
+    for (uint32_t w = threadIdx.x; w < S.num_prims * (uint32_t)(sizeof(Prim) / 16); w += kBlock) dst[w] = src[w];
+    __syncthreads();
+    S.nodes = &lds_nodes[0].n;
+    S.node_stride = (uint32_t)sizeof(LdsNode);
+    S.prims = lds_prims;
+}
+// LDS_LEVEL of the ray tracing kernels: 0 = scene in HBM, 1 = object table in LDS, 2 = object table, tree nodes and primitives in LDS
+DEV constexpr uint32_t ldsObjects(int level) { return level >= 1 ? kLdsObjectsTrace : 1; }
+DEV constexpr uint32_t ldsPrims(int level) { return level >= 2 ? kLdsTreePrims : 1; }
+
 // ---- trace ------------------------------------------------------------------------------------------------
-template <bool STATS, uint32_t LDS_OBJECTS>
+template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
     __shared__ uint32_t s_base;
-    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
+    __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
-    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
+    if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
+    if (LDS_LEVEL >= 2) stageTree(A.S, s_nodes, s_prims);
     const DScene& S = A.S;
     const uint64_t N = A.E.n;
     const uint64_t n2 = 2 * N;
@@ -183,14 +216,17 @@ __global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A0, uint32_t dep
 }
 
 // ---- connections: visibility, then evaluation -----------------------------------------------------------
-template <bool STATS, uint32_t LDS_OBJECTS>
+template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A0) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
-    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
+    __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
-    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
+    if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
+    if (LDS_LEVEL >= 2) stageTree(A.S, s_nodes, s_prims);
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
