@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
 }
 
 }  // namespace ub
+#include "lds_scene.h"
 #include "wavefront.h"
 namespace ub {
 
@@ -865,9 +866,22 @@ void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool s
     if (stats) hipLaunchKernelGGL(k_wf_bounce<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
     else hipLaunchKernelGGL(k_wf_bounce<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
 }
+// picks the instantiation (counting or not, how much of the scene fits into LDS) of a kernel template K<bool, int>
+#define UBDPT_LAUNCH_TRACE(K, ...)                                                                             \
+    do {                                                                                                       \
+        const int level_ = ldsLevelFor(A.S);                                                                   \
+        if (stats) {                                                                                           \
+            if (level_ == 2) hipLaunchKernelGGL((K<true, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);  \
+            else if (level_ == 1) hipLaunchKernelGGL((K<true, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<true, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);              \
+        } else {                                                                                               \
+            if (level_ == 2) hipLaunchKernelGGL((K<false, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__); \
+            else if (level_ == 1) hipLaunchKernelGGL((K<false, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<false, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);             \
+        }                                                                                                      \
+    } while (0)
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_wf_tail<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    else hipLaunchKernelGGL(k_wf_tail<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
+    UBDPT_LAUNCH_TRACE(k_wf_tail, A, depth);
 }
 void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
@@ -887,21 +901,6 @@ void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool sta
         } else {                                                                                               \
             if (lds_) hipLaunchKernelGGL((K<false, (CAP)>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);    \
             else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
-        }                                                                                                      \
-    } while (0)
-// the same for the ray tracing kernels K<bool, int>: how much of the scene fits into LDS
-#define UBDPT_LAUNCH_TRACE(K, ...)                                                                             \
-    do {                                                                                                       \
-        const bool obj_ = A.S.num_objects <= kLdsObjectsTrace;                                                 \
-        const bool tree_ = obj_ && A.S.accel == 0 && A.S.nodes && A.S.num_prims <= kLdsTreePrims;              \
-        if (stats) {                                                                                           \
-            if (tree_) hipLaunchKernelGGL((K<true, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);        \
-            else if (obj_) hipLaunchKernelGGL((K<true, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);    \
-            else hipLaunchKernelGGL((K<true, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);              \
-        } else {                                                                                               \
-            if (tree_) hipLaunchKernelGGL((K<false, 2>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);       \
-            else if (obj_) hipLaunchKernelGGL((K<false, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);   \
-            else hipLaunchKernelGGL((K<false, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);             \
         }                                                                                                      \
     } while (0)
 void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {

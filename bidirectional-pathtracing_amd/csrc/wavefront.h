@@ -392,9 +392,15 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
 }
 
 // ---- tail: survivors of the last wavefront bounce finish in a per-lane loop ---------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A, uint32_t depth) {
+template <bool STATS, int LDS_LEVEL>
+__global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
+    RenderArgs A = A0;
+    if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
+    if (LDS_LEVEL >= 2) stageTree(A.S, s_nodes, s_prims);
     const DScene& S = A.S;
     uint64_t N = A.E.n;
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;

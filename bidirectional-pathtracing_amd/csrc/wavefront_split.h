@@ -43,53 +43,6 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
     return pos;
 }
 
-// The object table (transforms, material, emitter data: 480 bytes per object) of a scene with few
-// objects is copied to LDS by every workgroup of a kernel instantiated with LDS_OBJECTS > 0. The
-// kernels read parts of a hit's object record at several points, each read depending on the one
-// before; from LDS such a read costs tens of cycles instead of a trip to L2. Every thread of the
-// workgroup must call this; the returned pointer replaces DScene::objects.
-constexpr uint32_t kLdsObjectsShade = 64;  // shading kernels hold 2 workgroups per CU
-constexpr uint32_t kLdsObjectsTrace = 32;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
-DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
-    static_assert(sizeof(DObject) % 16 == 0, "DObject is copied in 16-byte words");
-    const uint4* src = reinterpret_cast<const uint4*>(S.objects);
-    uint4* dst = reinterpret_cast<uint4*>(lds);
-    const uint32_t words = S.num_objects * (uint32_t)(sizeof(DObject) / 16);
-    for (uint32_t w = threadIdx.x; w < words; w += kBlock) dst[w] = src[w];
-    __syncthreads();
-    return lds;
-}
-
-// A scene of a few dozen primitives fits into LDS whole: tree nodes and primitives as well. A ray
-// then walks the tree without leaving the CU (traversal is a chain of dependent fetches, each of
-// which otherwise pays the latency of L2). Every thread of the workgroup must call this.
-constexpr uint32_t kLdsTreePrims = 48;
-// In LDS a node occupies 144 bytes: with the 128-byte stride of the HBM layout the lanes of a wave
-// that read the same field of different nodes would all hit the same few banks.
-struct __attribute__((aligned(16))) LdsNode {
-    BvhNode n;
-    uint32_t pad[4];
-};
-DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
-    static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
-    constexpr uint32_t kNodeWords = sizeof(BvhNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
-    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : S.num_prims;  // nodes of the binary tree the four-wide one is carved from
-    const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
-    uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
-    for (uint32_t w = threadIdx.x; w < n_nodes * kNodeWords; w += kBlock)
-        dst[(w / kNodeWords) * kLdsNodeWords + (w % kNodeWords)] = src[w];
-    src = reinterpret_cast<const uint4*>(S.prims);
-    dst = reinterpret_cast<uint4*>(lds_prims);
-    for (uint32_t w = threadIdx.x; w < S.num_prims * (uint32_t)(sizeof(Prim) / 16); w += kBlock) dst[w] = src[w];
-    __syncthreads();
-    S.nodes = &lds_nodes[0].n;
-    S.node_stride = (uint32_t)sizeof(LdsNode);
-    S.prims = lds_prims;
-}
-// LDS_LEVEL of the ray tracing kernels: 0 = scene in HBM, 1 = object table in LDS, 2 = object table, tree nodes and primitives in LDS
-DEV constexpr uint32_t ldsObjects(int level) { return level >= 1 ? kLdsObjectsTrace : 1; }
-DEV constexpr uint32_t ldsPrims(int level) { return level >= 2 ? kLdsTreePrims : 1; }
-
 // ---- trace ------------------------------------------------------------------------------------------------
 template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth) {

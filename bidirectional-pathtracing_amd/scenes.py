@@ -327,6 +327,23 @@ def tiny_scene(seed=0):
     return b.build()
 
 
+def many_spheres_scene(n_spheres, seed=0):
+    """Cornell shell plus a seeded cloud of small spheres of every material: a scene whose OBJECT count
+    (6 + n_spheres), not its triangle count, is the variable."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder(_cornell_camera())
+    _cornell_shell(b)
+    mats = [(capi.MAT_LATEX_PAINT, 0.0, 0.0), (capi.MAT_GLOSSY, 0.5, 0.3), (capi.MAT_PERFECT_MIRROR, 0.0, 0.0),
+            (capi.MAT_DIELECTRIC, 1.5, 0.0)]
+    for k in range(n_spheres):
+        c = rng.uniform(-0.8, 0.8, 3)
+        r = float(rng.uniform(0.04, 0.12))
+        m, a, bb = mats[k % len(mats)]
+        col = (1, 1, 1) if m == capi.MAT_DIELECTRIC else tuple(rng.uniform(0.3, 0.9, 3))
+        b.sphere(tuple(c), r, m, b.color(col), mat_a=a, mat_b=bb)
+    return b.build()
+
+
 CONFIGS = {
     # name: (scene factory, width, height, spp)
     "C1": (cornell_c1, 256, 256, 16),

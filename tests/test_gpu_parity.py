@@ -206,6 +206,38 @@ def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipe
     ctx.close()
 
 
+@pytest.mark.parametrize("n_spheres", [20, 30, 70])
+def test_image_parity_across_scene_sizes_that_change_the_memory_placement(oracle_mod, n_spheres):
+    """The kernels keep small scenes in LDS: tree, primitives and objects up to 48 primitives / 32 objects,
+    the object table alone up to 64 objects (shading), everything in HBM beyond. 26, 36 and 76 objects
+    select the three placements; the image must match the oracle path by path in each."""
+    w = h = 40
+    passes = 2
+    scene = scenes.many_spheres_scene(n_spheres, seed=n_spheres)
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(w, h)
+    opt = capi.Options()
+    opt.collect_stats = 1
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        got = ctx.read_sum()
+        s = ctx.stats()
+        rays = ray_batch(1 << 14, seed=7)
+        hits = ctx.intersect_batch(rays)
+    orc = oracle_mod.Oracle(scene, params, 32)
+    ref, cn = orc.render_passes(0, passes, SEED, num_threads=4, counters=True)
+    fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
+    bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
+    assert bad <= 0.02 and rm <= 2e-3, (bad, rm)
+    for k in ("eye_vertices", "light_vertices"):
+        assert abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2, (k, s[k], cn[k])
+    rh = orc.intersect_batch(rays)
+    m = rh["hit"] == 1
+    assert np.array_equal(hits["hit"], rh["hit"]) and np.array_equal(hits["object"][m], rh["object"][m])
+    assert np.array_equal(hits["d"][m].view(np.uint64), rh["d"][m].view(np.uint64))
+
+
 def test_pass_partition_is_additive(oracle_mod):
     """Passes {0..5} in one call == passes {0,2,4} + {1,3,5} with stride 2 (the multi-GPU partition),
     and a resumed render (upload_sum) continues the same sum."""
