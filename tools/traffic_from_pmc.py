@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turns a PMC summary (tools/pmc_summary.py) into profiles/traffic.json: HBM bytes per launch of
-every rendering kernel (the non-counting instantiation, `<false>`).
+every rendering kernel (the non-counting instantiation, `<false>` or `<false, placement>`).
 
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 
@@ -19,11 +19,12 @@ def main():
     d = json.load(open(src))
     out, detail = {}, {}
     for name, c in d.items():
-        if not name.endswith("<false>") or "FETCH_SIZE" not in c:
+        # the non-counting instantiations: k<false> or k<false, placement>
+        if "<false" not in name or "FETCH_SIZE" not in c:
             continue
         n = c["dispatches"]
         fetch_kib, write_kib = c["FETCH_SIZE"] / n, c.get("WRITE_SIZE", 0.0) / n
-        k = name[: -len("<false>")]
+        k = name.split("<")[0]
         out[k] = (2.0 * fetch_kib + write_kib) * 1024.0
         detail[k] = {"dispatches": n, "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
                      "uncorrected_bytes_per_launch": (fetch_kib + write_kib) * 1024.0}
