@@ -1,7 +1,7 @@
 // scene.h — flattened scene as it lives in HBM, shared by host and device code.
 //
 // Layout decisions (MI355X): everything a ray touches on the way down the tree is 16-byte aligned
-// and sized in whole 16-byte lanes (64-byte nodes, 48-byte primitives) so a lane fetches a node or a
+// and sized in whole 16-byte lanes (128-byte nodes, 48-byte primitives) so a lane fetches a node or a
 // primitive with dwordx4 loads; per-face shading attributes are kept apart from positions because
 // only the one winning face of a ray needs them.
 #pragma once

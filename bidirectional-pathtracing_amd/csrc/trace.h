@@ -1,7 +1,7 @@
 // trace.h — ray / scene intersection on the device.
 //
 // Replaces UScene::intersectionPoint and UScene::visibility (uengine/uscene.cpp:21-66), which scan
-// every object and every face. Here a ray walks a world-space LBVH (64-byte two-child nodes) with a
+// every object and every face. Here a ray walks a world-space LBVH (128-byte four-child nodes) with a
 // per-lane stack whose first kLdsStack entries live in LDS ([entry][lane], bank = lane, conflict
 // free) and whose rare overflow goes to a per-lane slice of HBM. Boxes are tested in fp32 with a
 // conservative slab test; candidate primitives are tested
