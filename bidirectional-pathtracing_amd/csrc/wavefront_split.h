@@ -22,6 +22,13 @@ constexpr uint32_t kQueueSentinel = 0xffffffffu;
 #ifndef UBDPT_TRACE_WAVES
 #define UBDPT_TRACE_WAVES 1
 #endif
+// the same for the shading and the connection evaluation kernel
+#ifndef UBDPT_SHADE_WAVES
+#define UBDPT_SHADE_WAVES 1
+#endif
+#ifndef UBDPT_EVAL_WAVES
+#define UBDPT_EVAL_WAVES 1
+#endif
 
 // Appends the lanes with pred to a queue with ONE global atomic per workgroup. Every lane of the
 // workgroup must call it. Returns the lane's slot (valid when pred).
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
 
 // ---- shade ------------------------------------------------------------------------------------------------
 template <bool STATS, uint32_t LDS_OBJECTS>
-__global__ __launch_bounds__(kBlock) void k_wf_shade(RenderArgs A0, uint32_t depth) {
+__global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderArgs A0, uint32_t depth) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
     __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(Rend
 // runs of equal target pixels are summed with shuffles and the first lane of a run issues the three
 // atomics. Atomic throughput, not arithmetic, limits this kernel.
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_pair_eval(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, UBDPT_EVAL_WAVES) void k_pair_eval(RenderArgs A) {
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
     const uint32_t lane = threadIdx.x & 63;

@@ -238,6 +238,71 @@ def test_image_parity_across_scene_sizes_that_change_the_memory_placement(oracle
     assert np.array_equal(hits["d"][m].view(np.uint64), rh["d"][m].view(np.uint64))
 
 
+@pytest.mark.parametrize("pipeline", [0, 2])
+@pytest.mark.parametrize("case", ["roulette_from_first_bounce", "strata_and_wide_lens", "non_square_tiny", "one_pixel"])
+def test_image_parity_for_other_render_parameters(oracle_mod, case, pipeline):
+    """Render parameters away from the GUI defaults: Russian roulette from the first bounce (min_depth 1; the
+    wavefront pipeline decides it before tracing), stratified pixel / lens samples with a wide lens and a near
+    focus plane, images that are not square and images of one pixel."""
+    w, h, passes, kw = {
+        "roulette_from_first_bounce": (40, 40, 3, dict(min_depth=1)),
+        "strata_and_wide_lens": (36, 36, 8, dict(pixel_subdiv=2, lens_subdiv=2, lens=0.05, focus=2.5)),
+        "non_square_tiny": (7, 3, 5, dict()),
+        "one_pixel": (1, 1, 9, dict(min_depth=2)),
+    }[case]
+    scene = scenes.tiny_scene() if case != "strata_and_wide_lens" else scenes.cornell_c2()
+    scene.desc.camera.ratio = w / h
+    params = scenes.make_params(w, h, **kw)
+    opt = capi.Options()
+    opt.collect_stats = 1
+    opt.pipeline = pipeline
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        got = ctx.read_sum()
+        s = ctx.stats()
+    orc = oracle_mod.Oracle(scene, params, 32)
+    ref, cn = orc.render_passes(0, passes, SEED, num_threads=2, counters=True)
+    fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
+    assert np.array_equal(np.isfinite(ref), np.isfinite(got))
+    bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
+    if w * h >= 400:
+        assert bad <= 0.02 and rm <= 2e-3, (bad, rm)
+    else:  # a handful of pixels: every one of them has to agree
+        assert bad == 0.0, (got, ref)
+    for k in ("eye_vertices", "light_vertices", "connections", "splats"):
+        assert abs(s[k] - cn[k]) <= 5e-3 * cn[k] + 2, (k, s[k], cn[k])
+    k = "closest_hit_rays"
+    assert s[k] <= cn[k] * (1 + 2e-3) + 2 and (pipeline == 0 or abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2), (k, s[k], cn[k])
+    if case == "roulette_from_first_bounce" and pipeline == 0:
+        assert s[k] < 0.97 * cn[k]  # the rays of the subpaths that lost the roulette were not traced
+
+
+def test_scene_without_emitters_and_empty_scene_render_black(oracle_mod):
+    """No emitter: light subpaths do not exist and nothing is ever added; no object at all: every ray misses."""
+    b = scenes.SceneBuilder(scenes.make_camera((0, 0, -3.4), (0, 0, 0), 0.69, 1.0))
+    grey = b.color((0.7, 0.7, 0.7))
+    b.sphere((0, 0, 0), 0.5, capi.MAT_LATEX_PAINT, grey)
+    b.mesh(scenes.quad((-1, -1, -1), (1, -1, -1), (1, -1, 1), (-1, -1, 1), (0, 1, 0), (1, 0, 0)), scenes.identity(),
+           capi.MAT_LATEX_PAINT, grey)
+    dark = b.build()
+    empty = scenes.SceneBuilder(scenes.make_camera((0, 0, -3.4), (0, 0, 0), 0.69, 1.0)).build()
+    params = scenes.make_params(16, 16)
+    for scene in (dark, empty):
+        for pipeline in (0, 1, 2, 3):
+            opt = capi.Options()
+            opt.collect_stats = 1
+            opt.pipeline = pipeline
+            with capi.Context(scene, params, opt) as ctx:
+                st, done = ctx.render_passes(0, 2, SEED)
+                assert st == capi.SUCCESS and done == 2
+                assert not ctx.read_sum().any()
+                s = ctx.stats()
+                assert s["light_vertices"] == 0 and s["shadow_rays"] == 0
+        ref = oracle_mod.Oracle(scene, params, 32).render_passes(0, 2, SEED)
+        assert not np.asarray(ref).any()
+
+
 def test_pass_partition_is_additive(oracle_mod):
     """Passes {0..5} in one call == passes {0,2,4} + {1,3,5} with stride 2 (the multi-GPU partition),
     and a resumed render (upload_sum) continues the same sum."""
