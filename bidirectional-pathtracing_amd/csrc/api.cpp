@@ -608,6 +608,8 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.fb = c->d_fb;
         A.first_pass = first_pass;
         A.path_offset = pos;
+        A.batch_pass0 = pos / c->npix;
+        A.batch_pixel0 = pos % c->npix;
         A.pass_stride = pass_stride;
         A.seed = seed;
         A.ovf = B.d_ovf; A.ovf_stride = A.E.n;

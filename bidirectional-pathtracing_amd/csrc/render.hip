@@ -69,16 +69,33 @@ DEV void fbAdd(double* fb, uint64_t npix, uint64_t pixel, d3 v) {
     unsafeAtomicAdd(fb + 2 * npix + pixel, v.z);
 }
 
+// Pixel-sample gid of the batch -> (index of its pass among the call's passes, pixel). The batch starts at pixel
+// batch_pixel0 of pass index batch_pass0; batch_pixel0 + gid and the pixel count almost always fit 32 bits, where
+// a division costs a fraction of the 64-bit one (every stage of every bounce decodes its path for the generator key).
+DEV void decodePassPixel(const RenderArgs& A, uint64_t gid, uint64_t& pass_index, uint64_t& pixel) {
+    const uint64_t npix = (uint64_t)A.S.img_res_x * A.S.img_res_y;
+    const uint64_t t = A.batch_pixel0 + gid;
+    uint64_t q;
+    if (((t | npix) >> 32) == 0) {
+        const uint32_t q32 = (uint32_t)t / (uint32_t)npix;
+        q = q32;
+        pixel = (uint32_t)t - q32 * (uint32_t)npix;
+    } else {
+        q = t / npix;
+        pixel = t - q * npix;
+    }
+    pass_index = A.batch_pass0 + q;
+}
+
 DEV void decodePath(const RenderArgs& A, uint64_t gid, uint64_t& pass, uint64_t& pixel, uint32_t& px, uint32_t& py) {
     // a batch is a contiguous range of the call's pixel-samples in (pass, pixel) order; it need not start or
     // end on a pass boundary
-    uint64_t npix = (uint64_t)A.S.img_res_x * A.S.img_res_y;
-    uint64_t g = A.path_offset + gid;
-    uint64_t pi = g / npix;
-    pixel = g - pi * npix;
+    uint64_t pi;
+    decodePassPixel(A, gid, pi, pixel);
     pass = A.first_pass + pi * A.pass_stride;
-    py = (uint32_t)(pixel / A.S.img_res_x);
-    px = (uint32_t)(pixel - (uint64_t)py * A.S.img_res_x);
+    // pixel < npix <= 2^32 and the width is below 2^16: a 32-bit division
+    py = (uint32_t)pixel / A.S.img_res_x;
+    px = (uint32_t)pixel - py * A.S.img_res_x;
 }
 
 // Everything between "a hit was found" and "the next ray is ready" is identical for both subpaths
@@ -505,8 +522,10 @@ DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
     if (t == 1) {
         if (STATS) ty.splat++;
         pixel = (uint64_t)tyy * S.img_res_x + tx;
-    } else
-        pixel = (A.path_offset + i) % npix;
+    } else {
+        uint64_t pass_index;
+        decodePassPixel(A, i, pass_index, pixel);
+    }
     value = vl.a * ve.a * c * w;
     return true;
 }
@@ -548,8 +567,11 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     if (t == 1) {
         if (STATS) ty.splat++;
         fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
-    } else
-        fbAdd(A.fb, npix, (A.path_offset + i) % npix, vl.a * ve.a * c * w);
+    } else {
+        uint64_t pass_index, pixel;
+        decodePassPixel(A, i, pass_index, pixel);
+        fbAdd(A.fb, npix, pixel, vl.a * ve.a * c * w);
+    }
 }
 
 // One lane per pixel-sample: appends its connectable (s,t) pairs to the pair queue. The specular
