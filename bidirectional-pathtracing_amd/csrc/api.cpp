@@ -113,6 +113,9 @@ struct ubdpt_context {
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
     uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
+    uint32_t shadow_budget = 0xffffffffu;  // traversal steps a shadow ray gets in the first round (0xffffffff: no second round)
+    uint32_t trace_budget = 0xffffffffu;   // the same for the closest-hit rays of the subpaths
+    uint32_t shadow_rounds = 2;           // 2 or 3: budget, (4 x budget,) unlimited; 3 measured no faster than 2
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
     unsigned long long pair_capacity = 0;
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
@@ -129,6 +132,9 @@ struct ubdpt_context {
         uint32_t* d_wf_hit_q = nullptr;
         uint64_t* d_vis_pairs = nullptr;
         uint32_t* d_vis_count = nullptr;
+        uint64_t* d_defer_pairs[2] = {nullptr, nullptr};  // allocated only when shadow rays get a step budget
+        uint32_t* d_defer_count = nullptr;                // two counters
+        uint32_t* d_wf_defer_q = nullptr;                 // allocated only when closest-hit rays get a step budget
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
@@ -234,7 +240,7 @@ struct ubdpt_context {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
             hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
-            hipFree(b.d_wf_hit_q); hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
+            hipFree(b.d_wf_hit_q); hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_defer_pairs[0]); hipFree(b.d_defer_pairs[1]); hipFree(b.d_defer_count); hipFree(b.d_wf_defer_q); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
         }
         hipFree(d_counters);
@@ -511,7 +517,13 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         }
         if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
         c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 8;
-        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
+        // a step budget for shadow rays pays where rays walk a tree in HBM; a scene that lives in LDS needs none
+        c->shadow_budget = 0xffffffffu;
+        c->trace_budget = 0xffffffffu;
+        if (c->opt.pipeline == 0 && c->S.accel == 0 && sceneLdsLevel(c->S) < 2) {
+            c->shadow_budget = c->opt.shadow_ray_budget ? c->opt.shadow_ray_budget : kDefaultShadowBudget;
+            c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : kDefaultClosestBudget;
+        }        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
         if (st != UBDPT_SUCCESS) break;
@@ -534,6 +546,10 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             ck(hipMalloc((void**)&b.d_wf_hit_q, sizeof(uint32_t) * (n2 + 64 * (n2 / 256 + 2))));
             ck(hipMalloc((void**)&b.d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
             ck(hipMalloc((void**)&b.d_vis_count, sizeof(uint32_t)));
+            ck(hipMalloc((void**)&b.d_defer_count, 2 * sizeof(uint32_t)));
+            if (c->shadow_budget != 0xffffffffu)
+                for (int k = 0; k < 2; k++) ck(hipMalloc((void**)&b.d_defer_pairs[k], sizeof(uint64_t) * c->pair_capacity));
+            if (c->trace_budget != 0xffffffffu) ck(hipMalloc((void**)&b.d_wf_defer_q, sizeof(uint32_t) * n2));
             ck(hipMalloc((void**)&b.d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
             ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
         }
@@ -617,6 +633,8 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
         A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
         A.wf_hit = B.d_wf_hit; A.wf_hit_q = B.d_wf_hit_q; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
+        for (int k = 0; k < 2; k++) { A.defer_pairs[k] = B.d_defer_pairs[k]; A.defer_count[k] = B.d_defer_count + k; }
+        A.wf_defer_q = B.d_wf_defer_q;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
@@ -647,7 +665,9 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
                 if (pl == 3) {
                     run(K_WF_BOUNCE, d == 0 ? units : 0, [&] { launchWfBounce(A, d, pblocks, stats, sm); });
                 } else {
-                    run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, pblocks, stats, sm); });
+                    run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, 0, c->trace_budget, pblocks, stats, sm); });
+                    if (c->trace_budget != 0xffffffffu)  // the rays that ran out of budget, together
+                        run(K_WF_TRACE, 0, [&] { launchWfTrace(A, d, 1, 0xffffffffu, pblocks, stats, sm); });
                     run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
                 }
             }
@@ -672,7 +692,18 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.ovf_stride = pstride;
             if (pl == 0) {
                 HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
-                run(K_PAIR_VISIBLE, units, [&] { launchPairVisible(A, pblocks, stats, sm); });
+                HIPCK(c, hipMemsetAsync(B.d_defer_count, 0, 2 * sizeof(uint32_t), sm));
+                if (c->shadow_budget == 0xffffffffu) {
+                    run(K_PAIR_VISIBLE, units, [&] { launchPairVisible(A, 0, 0xffffffffu, pblocks, stats, sm); });
+                } else {
+                    // rounds of growing budget; the rays that exceed one round's budget are traced again, together, in the next
+                    const uint32_t rounds = c->shadow_rounds;
+                    uint32_t budget = c->shadow_budget;
+                    for (uint32_t r = 0; r < rounds; r++, budget *= 4) {
+                        const uint32_t b = r + 1 == rounds ? 0xffffffffu : budget;
+                        run(K_PAIR_VISIBLE, r == 0 ? units : 0, [&] { launchPairVisible(A, r, b, pblocks, stats, sm); });
+                    }
+                }
                 run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
             } else {
                 run(K_PAIR_PROCESS, units, [&] { launchPairProcess(A, pblocks, stats, sm); });

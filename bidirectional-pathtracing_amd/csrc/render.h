@@ -28,8 +28,11 @@ struct RenderArgs {
     uint32_t* wf_hit_q;      // hit queue: id | region << 29, chunks padded to whole waves with 0xffffffff
     uint64_t* vis_pairs;     // connection pairs that passed the shadow ray
     uint32_t* vis_count;
+    uint64_t* defer_pairs[2];  // pairs whose shadow ray ran out of its step budget, written by round r to [r & 1] (null when no budget is used)
+    uint32_t* defer_count[2];
     uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
-    uint32_t* wf_count;      // [depth][16] queue lengths ([d][0] is used), zeroed before every batch
+    uint32_t* wf_count;      // [depth][16] queue lengths ([d][0] trace queue, [d][1] hit queue, [d][2] deferred rays), zeroed before every batch
+    uint32_t* wf_defer_q;    // [2n] ids of the rays of the current depth that ran out of their step budget (null when no budget is used)
 };
 
 constexpr uint32_t kMaxWfDepth = 30;  // most bounces that can run as wavefront launches before the tail loop takes over
@@ -37,12 +40,15 @@ constexpr int kWfQStride = 16;        // counters per depth: [0] trace queue len
 constexpr int kCarryDoubles = 16;     // two 64-byte lines per subpath
 constexpr int kCarryCountSlot = 7;    // the double of the first line that holds the subpath's count word
 constexpr int kHitDoubles = 4;        // half a line per subpath
+constexpr uint32_t kDefaultClosestBudget = 12; // the same for closest-hit rays; 10..12 measured best
+constexpr uint32_t kDefaultShadowBudget = 10;  // traversal steps of a shadow ray before it is deferred (large scenes); 8..12 measured best at 100 k and 2 M triangles
 void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
 void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
-void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
+void launchWfTrace(const RenderArgs& A, uint32_t depth, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s);
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
-void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
+int sceneLdsLevel(const DScene& S);  // 0 = scene in HBM, 1 = object table in LDS, 2 = tree and primitives too
+void launchPairVisible(const RenderArgs& A, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s);
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 
 constexpr int kNumCounters = 16;

@@ -47,6 +47,14 @@ DEV bool visible(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty) {
     return visibleBvh(S, p0, p1, st, STATS ? &ty.tc : nullptr);
 }
 
+// visibility with a step budget (trace.h); `first_try` = the ray has not been counted yet
+template <bool STATS>
+DEV int visibleBudget(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty, uint32_t budget, bool first_try) {
+    if (STATS && first_try) ty.shadow++;
+    if (S.accel == 1) return visibleLinear(S, p0, p1, STATS ? &ty.tc : nullptr) ? kVisible : kBlocked;
+    return visibleBvhBudget(S, p0, p1, st, STATS ? &ty.tc : nullptr, budget);
+}
+
 DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_v, uint32_t light_v) {
     atomicAdd(&counters[C_CLOSEST], (unsigned long long)ty.closest);
     atomicAdd(&counters[C_SHADOW], (unsigned long long)ty.shadow);
@@ -488,6 +496,22 @@ DEV bool pairVisible(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     if ((dot(ce, A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return false;
     return visible<STATS>(S, lpos, epos, st, ty);
 }
+// The same with a budget of traversal steps for the shadow ray: kBlocked (or rejected), kVisible, kOutOfBudget.
+template <bool STATS>
+DEV int pairVisibleBudget(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Stack& st, Tally& ty, uint32_t budget,
+                          bool first_try) {
+    const DScene& S = A.S;
+    d3 lpos = A.L.ld3(F_POS, s - 1, i);
+    d3 epos = A.E.ld3(F_POS, t - 1, i);
+    if (t == 1) {
+        uint32_t tx, tyy;
+        if (!t1Pixel(S, lpos, epos, tx, tyy)) return kBlocked;
+    }
+    d3 ce = lpos - epos;
+    ce = ce / sqrt(dot(ce, ce));
+    if ((dot(ce, A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return kBlocked;
+    return visibleBudget<STATS>(S, lpos, epos, st, ty, budget, first_try);
+}
 
 // Second half: connection factor and MIS weight (no ray is traced here). Returns the contribution and the
 // pixel it belongs to; false when the pair contributes nothing.
@@ -925,14 +949,16 @@ void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool sta
             else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
         }                                                                                                      \
     } while (0)
-void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth);
+void launchWfTrace(const RenderArgs& A, uint32_t depth, uint32_t round, uint32_t budget, unsigned blocks, bool stats,
+                   hipStream_t s) {
+    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth, round, budget);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
     UBDPT_LAUNCH_LDS(k_wf_shade, kLdsObjectsShade, A, depth);
 }
-void launchPairVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_pair_visible, A);
+int sceneLdsLevel(const DScene& S) { return ldsLevelFor(S); }
+void launchPairVisible(const RenderArgs& A, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s) {
+    UBDPT_LAUNCH_TRACE(k_pair_visible, A, round, budget);
 }
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);

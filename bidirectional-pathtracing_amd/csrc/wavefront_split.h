@@ -51,10 +51,16 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 }
 
 // ---- trace ------------------------------------------------------------------------------------------------
+// round 0 reads the trace queue of this depth and gives every ray `budget` traversal steps; a ray that runs out of
+// them leaves its closest candidate so far in its hit record and its id in the deferred queue, which round 1
+// (budget 0xffffffff) finishes: the long rays together instead of one per wave holding 63 idle lanes.
+// budget 0xffffffff in round 0: no ray is deferred and there is no round 1.
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth) {
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth, uint32_t round,
+                                                                         uint32_t budget) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
+    __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
     __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
@@ -69,8 +75,10 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    const uint64_t total = depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
-    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * n2;
+    const bool first = round == 0;
+    uint32_t* defer_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 2;
+    const uint64_t total = !first ? (uint64_t)*defer_cnt : depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = first ? A.wf_trace_q + (uint64_t)(depth & 1) * n2 : A.wf_defer_q;
     uint32_t* hit_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 1;
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
     Tally ty;
@@ -78,8 +86,9 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
         uint64_t j = base + tid;
         int region = kWfRegions;  // dead
         uint32_t id = 0;
+        bool deferred = false;
         if (j < total) {
-            id = depth == 0 ? (uint32_t)j : q[j];
+            id = (first && depth == 0) ? (uint32_t)j : q[j];
             bool light = id >= N;
             uint64_t i = light ? id - N : id;
             const PathStore& P = light ? A.L : A.E;
@@ -87,8 +96,18 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
             if (n > 0) {
                 Ray ray;
                 loadCarryRay(A, id, ray);
-                Closest hit = closestHit<STATS>(S, ray, st, ty);
-                if (hit.object >= 0) {
+                Closest hit;
+                if (first) {
+                    hit.d = __builtin_inf(); hit.u = 0; hit.v = 0; hit.object = -1; hit.face = 0;
+                    if (STATS) ty.closest++;
+                } else {
+                    loadHit(A, id, hit);  // the closest candidate round 0 had found when its budget ran out
+                }
+                if (S.accel == 1) hit = closestHitLinear(S, ray, STATS ? &ty.tc : nullptr);
+                else deferred = !closestHitBvhBudget(S, ray, st, STATS ? &ty.tc : nullptr, budget, hit);
+                if (deferred) {
+                    storeHit(A, id, hit);
+                } else if (hit.object >= 0) {
                     uint64_t pixel;
                     Rng rng = pathRng(A, i, light, pixel);
                     int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
@@ -98,6 +117,10 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderAr
                     }
                 }
             }
+        }
+        if (budget != 0xffffffffu) {  // uniform
+            uint32_t dpos = blockAppend(deferred, defer_cnt, s_wave, &s_base);
+            if (deferred) A.wf_defer_q[dpos] = id;
         }
         // stable counting sort of the chunk by region: rank inside the wave by ballot, wave totals in LDS
         uint32_t rank = 0;
@@ -176,8 +199,11 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
 }
 
 // ---- connections: visibility, then evaluation -----------------------------------------------------------
+// round 0 reads the pair queue, round r > 0 the deferred queue (r - 1) & 1. Every shadow ray gets a budget of
+// `budget` traversal steps; the pairs whose ray runs out of it go to the deferred queue r & 1 for the next round
+// (budget 0xffffffff: no ray is ever deferred; the last round must be launched with it).
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A0) {
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A0, uint32_t round, uint32_t budget) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
@@ -190,21 +216,33 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(Rend
     const uint32_t tid = threadIdx.x;
     const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    unsigned long long total = *A.pair_count;
+    const bool first = round == 0;
+    // (no dynamic index into the local copy A: it would be moved to scratch memory as a whole)
+    const bool odd = round & 1;
+    uint64_t* defer_q = odd ? A0.defer_pairs[1] : A0.defer_pairs[0];
+    uint32_t* defer_n = odd ? A0.defer_count[1] : A0.defer_count[0];
+    const uint64_t* prev_q = odd ? A0.defer_pairs[0] : A0.defer_pairs[1];
+    const uint32_t* prev_n = odd ? A0.defer_count[0] : A0.defer_count[1];
+    unsigned long long total = first ? *A.pair_count : (unsigned long long)*prev_n;
     if (total > A.pair_capacity) total = A.pair_capacity;
+    const uint64_t* queue = first ? A.pairs : prev_q;
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
     Tally ty;
     for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
         unsigned long long j = base + tid;
-        bool vis = false;
+        int r = kBlocked;
         uint64_t p = 0;
         if (j < total) {
-            p = A.pairs[j];
+            p = queue[j];
             uint32_t s = (uint32_t)((p >> 8) & 0xff), t = (uint32_t)(p & 0xff);
-            if (s != 0) vis = pairVisible<STATS>(A, p >> 16, s, t, st, ty);
+            if (s != 0) r = pairVisibleBudget<STATS>(A, p >> 16, s, t, st, ty, budget, first);
         }
-        uint32_t pos = blockAppend(vis, A.vis_count, s_wave, &s_base);
-        if (vis) A.vis_pairs[pos] = p;
+        uint32_t pos = blockAppend(r == kVisible, A.vis_count, s_wave, &s_base);
+        if (r == kVisible) A.vis_pairs[pos] = p;
+        if (budget != 0xffffffffu) {  // uniform; a deferred queue holds as many entries as the pair queue
+            pos = blockAppend(r == kOutOfBudget, defer_n, s_wave, &s_base);
+            if (r == kOutOfBudget) defer_q[pos] = p;
+        }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);

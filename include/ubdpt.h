@@ -127,6 +127,11 @@ typedef struct ubdpt_options {
     uint32_t streams;           /* batches in flight on separate HIP streams; 0 -> default, max 16 */
     uint32_t batch_pixel_samples; /* non-zero and below one pass: a batch is this many pixels of one pass
                                      (overrides passes_in_flight); small batches keep the path vertices cache-resident */
+    uint32_t shadow_ray_budget; /* scenes too large for on-chip copies: traversal steps a shadow ray may take before it is
+                                   set aside and finished in a second launch with the other long rays (the result is the
+                                   same); 0 -> default, 0xffffffff -> one launch, no budget */
+    uint32_t closest_ray_budget; /* the same for the closest-hit rays of the subpaths (a deferred ray keeps its closest
+                                    candidate and is finished in a second launch); 0 -> default, 0xffffffff -> off */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */

@@ -358,6 +358,31 @@ def test_sub_pass_batches_and_many_streams_do_not_change_the_result(pipeline):
     assert imgs[0].sum() > 0 and np.allclose(imgs[0], imgs[1], rtol=1e-12, atol=1e-12)
 
 
+def test_ray_step_budgets_do_not_change_the_result():
+    """A scene that does not fit into LDS gives every ray a budget of traversal steps and finishes the rays that
+    exceed it in a second launch. Budgets of 2 (nearly every ray is deferred), the defaults and no budget at all
+    must give the same image and the same vertex counts."""
+    scene = small_mesh_scene()
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(48, 48)
+    res = []
+    for shadow, closest in ((0xffffffff, 0xffffffff), (0, 0), (2, 2), (3, 0xffffffff), (0xffffffff, 5)):
+        opt = capi.Options()
+        opt.collect_stats = 1
+        opt.shadow_ray_budget = shadow
+        opt.closest_ray_budget = closest
+        with capi.Context(scene, params, opt) as ctx:
+            st, done = ctx.render_passes(0, 3, SEED)
+            assert st == capi.SUCCESS and done == 3
+            res.append((ctx.read_sum(), ctx.stats()))
+    img0, s0 = res[0]
+    assert img0.sum() > 0
+    for img, s in res[1:]:
+        assert np.allclose(img, img0, rtol=1e-12, atol=1e-12)
+        for k in ("closest_hit_rays", "shadow_rays", "eye_vertices", "light_vertices", "connections", "splats"):
+            assert s[k] == s0[k], k
+
+
 def test_path_cap_matches_oracle(oracle_mod):
     """With a small vertex cap both sides truncate the same subpaths."""
     scene, ctx, orc = make_pair(oracle_mod, "C2", w=32, h=32, maxv=4, stats=1)
