@@ -520,9 +520,10 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         // a step budget for shadow rays pays where rays walk a tree in HBM; a scene that lives in LDS needs none
         c->shadow_budget = 0xffffffffu;
         c->trace_budget = 0xffffffffu;
-        if (c->opt.pipeline == 0 && c->S.accel == 0 && sceneLdsLevel(c->S) < 2) {
-            c->shadow_budget = c->opt.shadow_ray_budget ? c->opt.shadow_ray_budget : kDefaultShadowBudget;
-            c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : kDefaultClosestBudget;
+        if (c->opt.pipeline == 0 && c->S.accel == 0) {
+            const bool in_lds = sceneLdsLevel(c->S) == 2;  // default there: no budget (measured: no gain)
+            c->shadow_budget = c->opt.shadow_ray_budget ? c->opt.shadow_ray_budget : in_lds ? 0xffffffffu : kDefaultShadowBudget;
+            c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
         }        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
