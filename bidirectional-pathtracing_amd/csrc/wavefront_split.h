@@ -30,6 +30,10 @@ constexpr uint32_t kQueueSentinel = 0xffffffffu;
 #define UBDPT_EVAL_WAVES 1
 #endif
 
+// (Workgroup b runs on XCD b % 8, each with its own L2. Remapping the chunks so that one XCD sweeps a contiguous
+// eighth of a queue — a band of the image for primary rays — was measured on scenes of 14, 100 k and 2 M
+// primitives: no difference, the rays that dominate are incoherent. The plain mapping stays.)
+
 // Appends the lanes with pred to a queue with ONE global atomic per workgroup. Every lane of the
 // workgroup must call it. Returns the lane's slot (valid when pred).
 DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_t* s_base) {
