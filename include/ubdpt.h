@@ -4,8 +4,9 @@
  * This is the drop-in boundary for the reference's renderer plug-in point
  *   class URenderer { initialize / renderPass / stop }   (uengine/urenderer.h:10-16)
  * as it is driven by UEngine                              (uengine/uengine.cpp:33-63,144-180,204-208).
- * A URenderer subclass living in the reference tree forwards to these entry points
- * (binding shown in INTEGRATION.md). Only plain pointers, sizes and POD structs cross
+ * A URenderer subclass living in the reference tree forwards to these entry points:
+ * initialize -> ubdpt_create, renderPass -> ubdpt_render_passes + ubdpt_read_sum,
+ * stop -> ubdpt_request_stop. Only plain pointers, sizes and POD structs cross
  * the boundary; every function returns an int status and never throws.
  *
  * Because UScene exposes geometry only through opaque virtuals

@@ -9,7 +9,10 @@
  *
  * PARITY UNPINNED: the reference ships no tests, golden vectors, fixtures or scene files, and it
  * cannot be built in this environment (it needs GLM and assimp, neither vendored nor installed),
- * so no output of the reference itself pins this restatement.  See DESIGN.md.
+ * so no output of the reference itself pins this restatement. What pins it instead: closed-form
+ * known-answer tests written from the reference's formulas, the aggregate figures of one probe run
+ * of the reference's sources (mean radiance, rays and vertices per pixel-sample of a Cornell box),
+ * and algorithmic invariants (tests/test_oracle_kat.py, test_oracle_anchors.py).
  */
 #ifndef ORACLE_API_H
 #define ORACLE_API_H
