@@ -32,6 +32,13 @@ pkg = importlib.import_module("bidirectional-pathtracing_amd")
 capi, scenes, multigpu = pkg.capi, pkg.scenes, pkg.multigpu
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+WORKLOADS = {
+    "C1": "Cornell box, two Lambertian spheres",
+    "C2": "Cornell box, dielectric + perfect-mirror spheres",
+    "C3": "Cornell box with 100 k-triangle textured meshes",
+    "C4": "Cornell box with 2 M-triangle meshes",
+    "C5": "Cornell box with 100 k-triangle meshes, Lambertian / glossy / mirror / dielectric",
+}
 
 
 def algorithmic_bytes(k):
@@ -244,7 +251,7 @@ def main():
             "metric": "bdpt_mpaths_per_s", "value": value, "unit": "Mpaths/s", "n_gpus": ngpu, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: Cornell box, dielectric + perfect-mirror spheres, {W}x{H}",
+            "config": {"workload": f"{args.config}: {WORKLOADS.get(args.config, 'synthetic scene')}, {W}x{H}",
                        "passes_per_step": pps, "spp_total": total_passes, "passes_per_gpu": args.steps * pps,
                        "accel": "lbvh" if args.accel == 0 else "linear", "pipeline": args.pipeline,
                        "passes_in_flight": args.passes_in_flight or "auto", "streams": args.streams or "default",
