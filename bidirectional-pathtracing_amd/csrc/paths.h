@@ -75,12 +75,18 @@ struct Vertex {
     double p_light_A, p_eye_A;
 };
 
+// A specular vertex is never the end of a connection (ubdptrenderer.cpp:604): all that is ever read
+// of it are the fields of line 0 (position for the neighbours' directions, the two pdfs and the flag
+// for the MIS walks), so only that line is written.
 DEV void storeVertex(const PathStore& P, uint32_t slot, uint64_t i, const Vertex& x) {
-    P.st3(F_POS, slot, i, x.sp.pos); P.st3(F_NG, slot, i, x.sp.Ng); P.st3(F_NS, slot, i, x.sp.Ns);
-    P.st3(F_TS, slot, i, x.sp.Ts);   P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
+    P.st3(F_POS, slot, i, x.sp.pos);
     P.st(F_PL, slot, i, x.p_light_A); P.st(F_PE, slot, i, x.p_eye_A);
-    P.st3(F_TEX, slot, i, x.tex);
     P.setObjFlags(slot, i, x.sp.object, ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0));
+    P.st(F_TEX, slot, i, x.tex.x); P.st(F_TEX + 1, slot, i, x.tex.y);
+    if (x.specular) return;
+    P.st(F_TEX + 2, slot, i, x.tex.z);
+    P.st3(F_NG, slot, i, x.sp.Ng); P.st3(F_NS, slot, i, x.sp.Ns);
+    P.st3(F_TS, slot, i, x.sp.Ts); P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
 }
 
 // The few fields of the last stored vertex that the subpath loop keeps in registers.
