@@ -18,10 +18,17 @@ namespace ub {
 
 constexpr uint32_t kQueueSentinel = 0xffffffffu;
 
-// waves per SIMD the ray-tracing kernels are compiled for (register budget = 512 / this)
+// Waves per SIMD the ray-tracing kernels are compiled for (register budget = 512 / this; 1 = whatever the
+// compiler needs, which comes to 4). A scene that lives in LDS leaves room for 4 workgroups per CU and its rays
+// are bound by arithmetic. Rays that walk a tree in HBM wait on dependent node fetches: for them a fifth wave per
+// SIMD is worth the handful of spilled registers it costs (+7 % on scenes of 100 k and 2 M triangles).
 #ifndef UBDPT_TRACE_WAVES
 #define UBDPT_TRACE_WAVES 1
 #endif
+#ifndef UBDPT_TRACE_WAVES_HBM
+#define UBDPT_TRACE_WAVES_HBM 5
+#endif
+constexpr int traceWaves(int lds_level) { return lds_level >= 2 ? UBDPT_TRACE_WAVES : UBDPT_TRACE_WAVES_HBM; }
 // the same for the shading and the connection evaluation kernel
 #ifndef UBDPT_SHADE_WAVES
 #define UBDPT_SHADE_WAVES 1
@@ -60,7 +67,7 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // (budget 0xffffffff) finishes: the long rays together instead of one per wave holding 63 idle lanes.
 // budget 0xffffffff in round 0: no ray is deferred and there is no round 1.
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace(RenderArgs A0, uint32_t depth, uint32_t round,
+__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth, uint32_t round,
                                                                          uint32_t budget) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
 // `budget` traversal steps; the pairs whose ray runs out of it go to the deferred queue r & 1 for the next round
 // (budget 0xffffffff: no ray is ever deferred; the last round must be launched with it).
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible(RenderArgs A0, uint32_t round, uint32_t budget) {
+__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_pair_visible(RenderArgs A0, uint32_t round, uint32_t budget) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
