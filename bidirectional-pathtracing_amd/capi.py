@@ -60,7 +60,8 @@ class Options(C.Structure):
     _fields_ = [("max_path_vertices", C.c_uint32), ("passes_in_flight", C.c_uint32), ("accel", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32), ("dense_threshold", C.c_uint32),
                 ("wavefront_depth", C.c_uint32), ("streams", C.c_uint32), ("batch_pixel_samples", C.c_uint32),
-                ("shadow_ray_budget", C.c_uint32), ("closest_ray_budget", C.c_uint32)]
+                ("shadow_ray_budget", C.c_uint32), ("closest_ray_budget", C.c_uint32),
+                ("pass_slots", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3)])
@@ -100,7 +101,7 @@ class Stats(C.Structure):
 EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
     "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
-    "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb",
+    "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
     "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
@@ -158,6 +159,8 @@ def load_library(path=None):
     lib.ubdpt_enqueue_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_synchronize.argtypes = [vp]
     lib.ubdpt_request_stop.argtypes = [vp]
+    lib.ubdpt_render_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
+    lib.ubdpt_read_sum_slot.argtypes = [vp, C.c_uint32, vp, C.c_int]
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
     lib.ubdpt_upload_sum.argtypes = [vp, vp]
@@ -229,6 +232,19 @@ class Context:
         st = self.lib.ubdpt_render_passes(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
         _check(st, "ubdpt_render_passes", allow=(STOPPED,))
         return st, done.value
+
+    def render_passes_separate(self, first_pass, n_passes, seed, pass_stride=1):
+        done = C.c_uint32(0)
+        st = self.lib.ubdpt_render_passes_separate(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
+        _check(st, "ubdpt_render_passes_separate", allow=(STOPPED,))
+        return st, done.value
+
+    def read_sum_slot(self, slot, out=None, add_into=False):
+        if out is None:
+            out = np.zeros((self.height, self.width, 3), np.float64)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (self.height, self.width, 3)
+        _check(self.lib.ubdpt_read_sum_slot(self.handle, slot, out.ctypes.data, 1 if add_into else 0), "ubdpt_read_sum_slot")
+        return out
 
     def enqueue_passes(self, first_pass, n_passes, seed, pass_stride=1):
         done = C.c_uint32(0)

@@ -108,8 +108,10 @@ struct ubdpt_context {
     DScene S{};
 
     uint64_t npix = 0;
-    double* d_fb = nullptr;       // planar
+    double* d_fb = nullptr;       // planar; the sum buffer, followed by pass_slots per-pass sum buffers
+    uint32_t pass_slots = 0;      // > 0: ubdpt_render_passes_separate keeps up to that many passes apart
     double* d_staging = nullptr;  // interleaved, npix * 3
+    double* h_staging = nullptr;  // pinned host mirror of d_staging, allocated on first use (read-backs that add into the caller's buffer)
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
     uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
@@ -236,6 +238,7 @@ struct ubdpt_context {
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
+        if (h_staging) { hipHostFree(h_staging); h_staging = nullptr; }
         for (auto& b : lanes) {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
@@ -524,11 +527,13 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             const bool in_lds = sceneLdsLevel(c->S) == 2;  // default there: no budget (measured: no gain)
             c->shadow_budget = c->opt.shadow_ray_budget ? c->opt.shadow_ray_budget : in_lds ? 0xffffffffu : kDefaultShadowBudget;
             c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
-        }        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
-        ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix));
+        }
+        c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
+        auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
+        ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix * (1 + c->pass_slots)));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
         if (st != UBDPT_SUCCESS) break;
-        ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix, c->stream));
+        ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix * (1 + c->pass_slots), c->stream));
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
         c->pair_capacity = c->cap_paths * 24;
         c->lanes.resize(nstreams);
@@ -596,13 +601,20 @@ static int finishPending(ubdpt_context* c) {
 }
 
 static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
-                        uint32_t* passes_done, bool wait) {
+                        uint32_t* passes_done, bool wait, bool separate = false) {
     if (passes_done) *passes_done = 0;
     if (!c) return UBDPT_INVALID_ARG;
+    if (separate && (c->pass_slots == 0 || n_passes > c->pass_slots)) return UBDPT_INVALID_ARG;
     if (pass_stride == 0) pass_stride = 1;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     c->stop = false;  // UBDPTRenderer::renderPass resets m_stop (ubdptrenderer.cpp:37)
+    if (separate) {   // the per-pass buffers of this call start from zero
+        int fs = finishPending(c);
+        if (fs != UBDPT_SUCCESS) return fs;
+        HIPCK(c, hipMemsetAsync(c->d_fb + 3 * c->npix, 0, sizeof(double) * 3 * c->npix * n_passes, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
     if (!c->work_pending) { c->work_pending = true; c->pending_since = nowSeconds(); }
     bool stats = c->opt.collect_stats != 0;
     uint32_t done = 0;
@@ -623,6 +635,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.E = B.E; A.L = B.L;
         A.E.n = A.L.n = nbatch;
         A.fb = c->d_fb;
+        A.fb_slots = separate ? c->pass_slots : 0;
         A.first_pass = first_pass;
         A.path_offset = pos;
         A.batch_pass0 = pos / c->npix;
@@ -741,6 +754,11 @@ int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passe
     return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_enqueued, false);
 }
 
+int ubdpt_render_passes_separate(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride,
+                                 uint64_t seed, uint32_t* passes_done) {
+    return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_done, true, true);
+}
+
 int ubdpt_synchronize(ubdpt_context* c) {
     if (!c) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
@@ -765,23 +783,36 @@ int ubdpt_read_sum_device(ubdpt_context* c, double* device_rgb) {
     return UBDPT_SUCCESS;
 }
 
-int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
-    if (!c || !rgb) return UBDPT_INVALID_ARG;
+// buffer 0 is the sum buffer, buffer 1 + k the per-pass buffer k
+static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add_into) {
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
-    launchInterleave(c->d_fb, c->npix, c->d_staging, c->stream);
+    launchInterleave(c->d_fb + (uint64_t)buffer * 3 * c->npix, c->npix, c->d_staging, c->stream);
     HIPCK(c, hipGetLastError());
     if (!add_into) {
         HIPCK(c, hipMemcpyAsync(rgb, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
     } else {
-        std::vector<double> tmp(3 * c->npix);
-        HIPCK(c, hipMemcpyAsync(tmp.data(), c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
+        // the reference-shaped renderPass comes here once per pass: a pinned staging buffer kept for the life of the
+        // context (no page faults, full PCIe rate) instead of a fresh pageable one per call
+        if (!c->h_staging) HIPCK(c, hipHostMalloc((void**)&c->h_staging, sizeof(double) * 3 * c->npix, hipHostMallocDefault));
+        HIPCK(c, hipMemcpyAsync(c->h_staging, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
+        const double* tmp = c->h_staging;
         for (uint64_t i = 0; i < 3 * c->npix; i++) rgb[i] += tmp[i];
     }
     return UBDPT_SUCCESS;
+}
+
+int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
+    if (!c || !rgb) return UBDPT_INVALID_ARG;
+    return readSumBuffer(c, 0, rgb, add_into);
+}
+
+int ubdpt_read_sum_slot(ubdpt_context* c, uint32_t slot, double* rgb, int add_into) {
+    if (!c || !rgb || slot >= c->pass_slots) return UBDPT_INVALID_ARG;
+    return readSumBuffer(c, 1 + slot, rgb, add_into);
 }
 
 // uengine/uconverter.cpp:3-76: the fit functions and their sums over the three wavelength bins

@@ -14,6 +14,7 @@ struct RenderArgs {
     double* fb;            // planar sum buffer: R[npix], G[npix], B[npix]
     uint64_t first_pass, pass_stride, seed;
     uint64_t path_offset;  // index of the batch's first pixel-sample among the call's n_passes * npix
+    uint64_t fb_slots;     // > 0: the pass with index j among the call's passes adds into per-pass sum buffer j % fb_slots (they follow fb)
     uint64_t batch_pass0;  // path_offset / npix and path_offset % npix, split on the host: the kernels then divide
     uint64_t batch_pixel0; // (batch_pixel0 + i), a number that almost always fits 32 bits, instead of a 64-bit index
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]

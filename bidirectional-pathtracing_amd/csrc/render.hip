@@ -95,6 +95,16 @@ DEV void decodePassPixel(const RenderArgs& A, uint64_t gid, uint64_t& pass_index
     pass_index = A.batch_pass0 + q;
 }
 
+// With fb_slots > 0 the passes of a call are kept apart: the pass with index j among the call's passes adds into
+// per-pass sum buffer j % fb_slots; these follow the sum buffer proper, 3 * npix doubles each. Returns the offset
+// for the pixel-sample gid of the batch; it is added to the pixel index handed to fbAdd.
+DEV uint64_t fbSlotOffset(const RenderArgs& A, uint64_t gid) {
+    if (A.fb_slots == 0) return 0;
+    uint64_t pass_index, pixel;
+    decodePassPixel(A, gid, pass_index, pixel);
+    return (1 + pass_index % A.fb_slots) * 3ull * ((uint64_t)A.S.img_res_x * A.S.img_res_y);
+}
+
 DEV void decodePath(const RenderArgs& A, uint64_t gid, uint64_t& pass, uint64_t& pixel, uint32_t& px, uint32_t& py) {
     // a batch is a contiguous range of the call's pixel-samples in (pass, pixel) order; it need not start or
     // end on a pass boundary
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
         }
     }
     E.setMeta(gid, n | smask);
-    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel + fbSlotOffset(A, gid), I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -450,12 +460,12 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
             if (t == 1) {
                 d3 I_t1 = vl.a * lens_a * c * w;
                 if (STATS) { ty.splat++; ty.fb++; }
-                fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, I_t1);
+                fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx + fbSlotOffset(A, gid), I_t1);
             } else
                 I = I + vl.a * ve.a * c * w;
         }
     }
-    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+    if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel + fbSlotOffset(A, gid), I); if (STATS) ty.fb++; }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -550,6 +560,7 @@ DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
         uint64_t pass_index;
         decodePassPixel(A, i, pass_index, pixel);
     }
+    pixel += fbSlotOffset(A, i);  // index into the sum buffers of all slots
     value = vl.a * ve.a * c * w;
     return true;
 }
@@ -590,11 +601,11 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     if (STATS) { ty.conn++; ty.fb++; }
     if (t == 1) {
         if (STATS) ty.splat++;
-        fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx, vl.a * ve.a * c * w);
+        fbAdd(A.fb, npix, (uint64_t)tyy * S.img_res_x + tx + fbSlotOffset(A, i), vl.a * ve.a * c * w);
     } else {
         uint64_t pass_index, pixel;
         decodePassPixel(A, i, pass_index, pixel);
-        fbAdd(A.fb, npix, pixel, vl.a * ve.a * c * w);
+        fbAdd(A.fb, npix, pixel + fbSlotOffset(A, i), vl.a * ve.a * c * w);
     }
 }
 

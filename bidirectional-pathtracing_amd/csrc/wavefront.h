@@ -152,7 +152,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
             nv.sp.pos = transformPoint(obj.W, nv.sp.pos);
             nv.sp.Ns = transformVectorT(obj.invW, nv.sp.Ns);
             d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
-            if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+            if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel + fbSlotOffset(A, i), I); if (STATS) ty.fb++; }
         }
         return false;
     }
@@ -170,7 +170,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     finishVertex(obj, nv, dirT);
     if (emits) {
         d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
-        if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel, I); if (STATS) ty.fb++; }
+        if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel + fbSlotOffset(A, i), I); if (STATS) ty.fb++; }
     }
     storeVertex(P, n, i, nv);
     n++;

@@ -24,19 +24,36 @@ bool HipRenderer::initialize(const RenderParameters& render_params, std::shared_
     ubdpt_scene_desc desc;
     std::memset(&desc, 0, sizeof(desc));
     if (!scene->flatten(desc)) { m_status = UBDPT_INVALID_SCENE; return false; }
-    m_status = ubdpt_create(&desc, &render_params, &m_options, m_device, &m_ctx);
+    // window of passes rendered at once for renderPass: about 4 M pixel-samples, at most 32 passes
+    ubdpt_options opt = m_options;
+    if (opt.pass_slots == 0) {
+        const uint64_t npix = (uint64_t)render_params.img_res_x * render_params.img_res_y;
+        opt.pass_slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, npix ? (1ull << 22) / npix : 1));
+    }
+    m_window_slots = std::min<uint32_t>(opt.pass_slots, 64);
+    m_window_count = 0;
+    m_status = ubdpt_create(&desc, &render_params, &opt, m_device, &m_ctx);
     return m_status == UBDPT_SUCCESS;
 }
 
 bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t /*num_threads*/,
                              std::function<void(double)>& update_progress_callback) {
     if (!m_ctx || !pixel_buffer) { m_status = UBDPT_UNINITIALIZED; return false; }
-    // the device sum holds this pass only; it is then added to the caller's running sum
-    if ((m_status = ubdpt_upload_sum(m_ctx, nullptr)) != UBDPT_SUCCESS) return false;
-    uint32_t done = 0;
-    m_status = ubdpt_render_passes(m_ctx, curr_pass, 1, 1, m_seed, &done);
-    if (m_status != UBDPT_SUCCESS || done != 1) return false;   // stopped: the engine drops the write buffer
-    if ((m_status = ubdpt_read_sum(m_ctx, pixel_buffer->ptr(), 1)) != UBDPT_SUCCESS) return false;
+    m_stop_requested = false;  // UBDPTRenderer::renderPass resets m_stop on entry (ubdptrenderer.cpp:37)
+    const bool in_window = m_window_count != 0 && m_window_seed == m_seed && curr_pass >= m_window_first &&
+                           curr_pass < m_window_first + m_window_count;
+    if (!in_window) {
+        // passes curr_pass .. curr_pass + slots - 1, each into its own device sum buffer
+        m_window_count = 0;
+        uint32_t done = 0;
+        m_status = ubdpt_render_passes_separate(m_ctx, curr_pass, m_window_slots, 1, m_seed, &done);
+        if (m_status != UBDPT_SUCCESS || done == 0) return false;   // stopped: the engine drops the write buffer
+        m_window_first = curr_pass; m_window_count = done; m_window_seed = m_seed;
+    }
+    // this pass is added to the caller's running sum
+    m_status = ubdpt_read_sum_slot(m_ctx, (uint32_t)(curr_pass - m_window_first), pixel_buffer->ptr(), 1);
+    if (m_status != UBDPT_SUCCESS) return false;
+    if (m_stop_requested) { m_status = UBDPT_STOPPED; m_window_count = 0; return false; }  // stop() arrived during this call
     if (update_progress_callback != nullptr) {
         std::lock_guard<std::mutex> lock(m_progress_mutex);
         update_progress_callback(1.0);
@@ -45,6 +62,7 @@ bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t cur
 }
 
 void HipRenderer::stop() {
+    m_stop_requested = true;
     if (m_ctx) ubdpt_request_stop(m_ctx);
 }
 

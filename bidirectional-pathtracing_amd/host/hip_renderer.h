@@ -101,6 +101,15 @@ private:
     uint64_t m_seed = 0x5EED;
     int m_status = UBDPT_SUCCESS;
     std::mutex m_progress_mutex;  // the reference serialises its progress callback (ubdptrenderer.cpp:54-62)
+    // renderPass hands back one pass per call, but one pass is a small batch for the device (a fraction of a
+    // millisecond of work behind two dozen launches). The adapter therefore renders a window of consecutive passes
+    // at once into separate device sum buffers (ubdpt_render_passes_separate) and serves the following calls from
+    // it; a call outside the window (or after initialize or a change of seed) starts a new one. The device sum the
+    // batched entry points work on is a different buffer and is not disturbed.
+    uint32_t m_window_slots = 1;
+    size_t m_window_first = 0, m_window_count = 0;
+    uint64_t m_window_seed = 0;
+    std::atomic<bool> m_stop_requested{false};
 };
 
 class HipEngine {

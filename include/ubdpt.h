@@ -133,6 +133,8 @@ typedef struct ubdpt_options {
                                    same); 0 -> default, 0xffffffff -> one launch, no budget */
     uint32_t closest_ray_budget; /* the same for the closest-hit rays of the subpaths (a deferred ray keeps its closest
                                     candidate and is finished in a second launch); 0 -> default, 0xffffffff -> off */
+    uint32_t pass_slots;        /* per-pass sum buffers held on the device besides the sum buffer (0: none, max 64);
+                                   ubdpt_render_passes_separate keeps up to that many passes of a call apart */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */
@@ -253,6 +255,18 @@ int ubdpt_read_sum(ubdpt_context* ctx, double* rgb, int add_into);
 int ubdpt_read_sum_device(ubdpt_context* ctx, double* device_rgb);
 /* Replaces the device sum (resume from a .ur file, uengine/uengine.cpp:107-116). NULL clears it. */
 int ubdpt_upload_sum(ubdpt_context* ctx, const double* rgb);
+
+/*
+ * For a caller that must hand back ONE pass at a time, as URenderer::renderPass does
+ * (uengine/uengine.cpp:153-164: the engine owns the running sum and adds one pass per call), but
+ * wants the device to work on batches of passes: the n_passes <= ubdpt_options.pass_slots passes of
+ * the call are rendered together, the pass with index j among them adding into per-pass buffer j
+ * (cleared first) instead of the device sum, which this call leaves alone. ubdpt_read_sum_slot then
+ * delivers the passes one by one. The samples of a pass do not depend on what it is batched with.
+ */
+int ubdpt_render_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
+                                 uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
+int ubdpt_read_sum_slot(ubdpt_context* ctx, uint32_t slot, double* rgb, int add_into);
 
 /* UScene::intersectionPoint (uengine/uscene.cpp:41-66) for n rays, through the backend's accelerator. */
 int ubdpt_intersect_batch(ubdpt_context* ctx, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);

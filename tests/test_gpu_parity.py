@@ -327,6 +327,44 @@ def test_pass_partition_is_additive(oracle_mod):
     ctx.close()
 
 
+@pytest.mark.parametrize("pipeline", [0, 1, 2, 3])
+def test_separate_passes_equal_the_passes_rendered_alone(pipeline):
+    """ubdpt_render_passes_separate renders a window of passes as one batch but keeps their sums apart: every
+    per-pass buffer must equal that pass rendered alone, their total the ordinary render of the window, and the
+    device sum proper must be left untouched."""
+    scene = SCENES["C2"]()
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(40, 40)
+    opt = capi.Options()
+    opt.pipeline = pipeline
+    opt.pass_slots = 5
+    with capi.Context(scene, params, opt) as ctx:
+        ctx.render_passes(100, 2, SEED)
+        resident = ctx.read_sum()
+        st, done = ctx.render_passes_separate(7, 5, SEED)
+        assert st == capi.SUCCESS and done == 5
+        slots = [ctx.read_sum_slot(k) for k in range(5)]
+        assert np.array_equal(ctx.read_sum(), resident)
+        # a second, shorter window: its buffers start from zero again
+        ctx.render_passes_separate(3, 2, SEED)
+        again = [ctx.read_sum_slot(k) for k in range(2)]
+        with pytest.raises(Exception):
+            ctx.render_passes_separate(0, 6, SEED)
+        ctx.upload_sum(None)
+        alone = []
+        for p in (7, 8, 9, 10, 11, 3, 4):
+            ctx.upload_sum(None)
+            ctx.render_passes(p, 1, SEED)
+            alone.append(ctx.read_sum())
+        ctx.upload_sum(None)
+        ctx.render_passes(7, 5, SEED)
+        window = ctx.read_sum()
+    for k in range(5):
+        assert slots[k].sum() > 0 and np.allclose(slots[k], alone[k], rtol=1e-12, atol=1e-12), k
+    assert np.allclose(again[0], alone[5], rtol=1e-12, atol=1e-12) and np.allclose(again[1], alone[6], rtol=1e-12, atol=1e-12)
+    assert np.allclose(sum(slots), window, rtol=1e-12, atol=1e-12)
+
+
 def test_passes_in_flight_does_not_change_the_result(oracle_mod):
     a = make_pair(oracle_mod, "C1", w=32, h=32, pif=1)[1]
     b = make_pair(oracle_mod, "C1", w=32, h=32, pif=5)[1]
