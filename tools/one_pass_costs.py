@@ -1,5 +1,12 @@
-import importlib, os, sys, time
-sys.path.insert(0, "/root/repo")
+"""Costs of the pieces of one reference-shaped renderPass on C2 512x512: one pass rendered alone, clearing the
+device sum, reading it back (with and without adding into the caller's buffer), a host copy of the buffer."""
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 pkg = importlib.import_module("bidirectional-pathtracing_amd")
 capi, scenes = pkg.capi, pkg.scenes
 import numpy as np
