@@ -365,6 +365,29 @@ def test_separate_passes_equal_the_passes_rendered_alone(pipeline):
     assert np.allclose(sum(slots), window, rtol=1e-12, atol=1e-12)
 
 
+def test_full_size_headline_workload_properties(oracle_mod):
+    """The benchmark configuration at its full size (C2, 512 x 512): too large for a path-by-path comparison in a
+    test, so size-independent properties are checked. 64 passes in one call equal the even plus the odd passes
+    (the multi-GPU partition), every pixel is finite and nearly all received light, and the mean radiance agrees with the
+    oracle's at a size the oracle finishes in a second (the image mean does not depend on the resolution)."""
+    scene, params, _ = scenes.make_config("C2")
+    with capi.Context(scene, params) as ctx:
+        ctx.render_passes(0, 64, SEED)
+        full = ctx.read_sum()
+        ctx.upload_sum(None)
+        ctx.render_passes(0, 32, SEED, pass_stride=2)
+        ctx.render_passes(1, 32, SEED, pass_stride=2)
+        halves = ctx.read_sum()
+    assert np.isfinite(full).all() and (full >= 0).all() and (full.sum(axis=2) > 0).mean() > 0.95
+    assert np.allclose(full, halves, rtol=1e-11, atol=1e-11)
+    small = scenes.make_params(96, 96)
+    sc2 = scenes.cornell_c2()
+    sc2.desc.camera.ratio = 1.0
+    ref = oracle_mod.Oracle(sc2, small, 32).render_passes(0, 32, SEED + 1, num_threads=4)
+    m_gpu, m_ref = full.reshape(-1, 3).mean(0) / 64, ref.reshape(-1, 3).mean(0) / 32
+    assert np.all(np.abs(m_gpu - m_ref) <= 0.02 * m_ref), (m_gpu, m_ref)
+
+
 def test_passes_in_flight_does_not_change_the_result(oracle_mod):
     a = make_pair(oracle_mod, "C1", w=32, h=32, pif=1)[1]
     b = make_pair(oracle_mod, "C1", w=32, h=32, pif=5)[1]
