@@ -203,6 +203,8 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
 }
 
 // ---- generation ---------------------------------------------------------------------------------------
+// Vertex 0 and the first ray of every subpath (eye: lens vertex and primary ray, :231-257; light: emitter vertex and
+// emission ray, :413-454): stores the vertex, the count word and the carry record.
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
     uint64_t id = (uint64_t)blockIdx.x * kBlock + threadIdx.x;

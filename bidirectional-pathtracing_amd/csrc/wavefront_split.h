@@ -66,6 +66,8 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // them leaves its closest candidate so far in its hit record and its id in the deferred queue, which round 1
 // (budget 0xffffffff) finishes: the long rays together instead of one per wave holding 63 idle lanes.
 // budget 0xffffffff in round 0: no ray is deferred and there is no round 1.
+// (Generating the subpaths inside the first launch of this kernel instead of in k_wf_gen was measured: the generation
+// code costs the kernel a quarter of its occupancy, inlined or not, and the whole is slower: 411 against 418 Mpaths/s.)
 template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth, uint32_t round,
                                                                          uint32_t budget) {
