@@ -34,15 +34,30 @@ struct Carry {
                      // surface to continue from (the reference writes it only then, :379-395 / :568-584)
 };
 
-DEV void loadCarry(const RenderArgs& A, uint64_t id, Carry& c) {
+// `primary_eye`: an eye subpath before its first bounce. The second line of its record would hold constants
+// (throughput 1, the lens normal, no roulette, nothing pending); k_wf_gen does not write them and they are made here.
+DEV void loadCarry(const RenderArgs& A, uint64_t id, Carry& c, bool primary_eye) {
     const double* p = A.carry + id * kCarryDoubles;
     c.pos = mk3(p[0], p[1], p[2]);
     c.dir = mk3(p[3], p[4], p[5]);
     c.p_psa = p[6];
-    c.a = mk3(p[8], p[9], p[10]);
-    c.Ns = mk3(p[11], p[12], p[13]);
-    c.q = p[14];
-    c.pending = p[15];
+    if (primary_eye) {
+        c.a = mk3(1.0, 1.0, 1.0);
+        c.Ns = transformVector(A.S.invV, mk3(0, 0, 1));
+        c.q = 1.0;
+        c.pending = 0;
+    } else {
+        c.a = mk3(p[8], p[9], p[10]);
+        c.Ns = mk3(p[11], p[12], p[13]);
+        c.q = p[14];
+        c.pending = p[15];
+    }
+}
+DEV void storeCarryRay(const RenderArgs& A, uint64_t id, const Carry& c) {  // first line only
+    double* p = A.carry + id * kCarryDoubles;
+    p[0] = c.pos.x; p[1] = c.pos.y; p[2] = c.pos.z;
+    p[3] = c.dir.x; p[4] = c.dir.y; p[5] = c.dir.z;
+    p[6] = c.p_psa;
 }
 DEV void loadCarryRay(const RenderArgs& A, uint64_t id, Ray& r) {
     const double* p = A.carry + id * kCarryDoubles;
@@ -276,7 +291,10 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
         } else {
             A.L.setMeta(i, 0);
         }
-        if (live) storeCarry(A, id, cy);
+        if (live) {
+            if (light) storeCarry(A, id, cy);
+            else storeCarryRay(A, id, cy);  // the rest of an eye subpath's first record is constant, see loadCarry
+        }
     }
 }
 
@@ -366,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
             uint64_t pixel;
             Rng rng = pathRng(A, i, light, pixel);
             Carry cy;
-            loadCarry(A, sid, cy);
+            loadCarry(A, sid, cy, !light && n == 1);
             cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, h2, lobe, cy, ty)
                          : shadeStep<STATS, false>(A, i, pixel, rng, n, h2, lobe, cy, ty);
             if (cont) storeCarry(A, sid, cy);
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A0, uint32_t dept
         uint64_t pixel;
         Rng rng = pathRng(A, i, light, pixel);
         Carry cy;
-        loadCarry(A, id, cy);
+        loadCarry(A, id, cy, !light && n == 1);
         for (;;) {
             Ray ray;
             ray.o = cy.pos; ray.d = cy.dir;

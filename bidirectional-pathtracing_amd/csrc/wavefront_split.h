@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
                 uint64_t pixel;
                 Rng rng = pathRng(A, i, light, pixel);
                 Carry cy;
-                loadCarry(A, id, cy);
+                loadCarry(A, id, cy, !light && n == 1);
                 Closest hit;
                 loadHit(A, id, hit);
                 cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
