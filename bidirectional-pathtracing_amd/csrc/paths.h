@@ -175,6 +175,27 @@ DEV void loadConn(const PathStore& P, uint32_t slot, uint64_t i, ConnVertex& c) 
     c.lobe = (f & 0xff) - 1;
     c.specular = (f >> 8) & 1;
 }
+// The lens vertex (slot 0 of an eye subpath): only its position varies, so only line 0 of its record is stored
+// and the rest is made here (the values computeEyeSubpath gives it, ubdptrenderer.cpp:231-246).
+DEV d3 lensNormal(const DScene& S) { return transformVector(S.invV, mk3(0, 0, 1)); }
+DEV void loadConnEye(const DScene& S, const PathStore& E, uint32_t slot, uint64_t i, ConnVertex& c) {
+    if (slot != 0) { loadConn(E, slot, i, c); return; }
+    c.pos = E.ld3(F_POS, 0, i);
+    c.p_light_A = E.ld(F_PL, 0, i); c.p_eye_A = E.ld(F_PE, 0, i);
+    c.Ng = c.Ns = lensNormal(S);
+    c.Ts = transformVector(S.invV, mk3(1, 0, 0));
+    c.Bs = transformVector(S.invV, mk3(0, 1, 0));
+    c.a = mk3(1.0, 1.0, 1.0);
+    c.tex = mk3(0, 0, 0);
+    c.object = -1; c.lobe = -1; c.specular = false;
+}
+DEV void storeLensVertex(const PathStore& E, uint64_t i, const Vertex& x) {
+    E.st3(F_POS, 0, i, x.sp.pos);
+    E.st(F_PL, 0, i, x.p_light_A); E.st(F_PE, 0, i, x.p_eye_A);
+    E.setObjFlags(0, i, x.sp.object, ((x.sp.lobe + 1) & 0xff));
+    E.st(F_TEX, 0, i, 0.0); E.st(F_TEX + 1, 0, i, 0.0);
+}
+
 DEV Frame frameOf(const ConnVertex& c) { Frame f; f.Ng = c.Ng; f.Ns = c.Ns; f.Ts = c.Ts; f.Bs = c.Bs; return f; }
 
 // Projects a light vertex onto the image plane (ubdptrenderer.cpp:111-131). Returns false when the

@@ -437,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
     if (STATS) { Tally t0; flushTally(t0, A.counters, nE, nL); }
     d3 I = mk3(0, 0, 0);
     d3 lens_pos = E.ld3(F_POS, 0, gid);
-    d3 lens_a = E.ld3(F_A, 0, gid);
+    d3 lens_a = mk3(1.0, 1.0, 1.0);  // the lens vertex's throughput (only line 0 of its record is stored)
     for (uint32_t s = 1; s <= nL; s++) {
         ConnVertex vl;
         loadConn(L, s - 1, gid, vl);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
             }
             if (E.specular(t - 1, gid)) continue;
             ConnVertex ve;
-            loadConn(E, t - 1, gid, ve);
+            loadConnEye(S, E, t - 1, gid, ve);
             if (!visible<STATS>(S, vl.pos, ve.pos, st, ty)) continue;
             d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, gid) : mk3(0, 0, 0);
             d3 c;
@@ -503,7 +503,7 @@ DEV bool pairVisible(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     }
     d3 ce = lpos - epos;
     ce = ce / sqrt(dot(ce, ce));
-    if ((dot(ce, A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return false;
+    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return false;
     return visible<STATS>(S, lpos, epos, st, ty);
 }
 // The same with a budget of traversal steps for the shadow ray: kBlocked (or rejected), kVisible, kOutOfBudget.
@@ -519,7 +519,7 @@ DEV int pairVisibleBudget(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t 
     }
     d3 ce = lpos - epos;
     ce = ce / sqrt(dot(ce, ce));
-    if ((dot(ce, A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return kBlocked;
+    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return kBlocked;
     return visibleBudget<STATS>(S, lpos, epos, st, ty, budget, first_try);
 }
 
@@ -535,7 +535,7 @@ DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally
     // (the positions before the end vertices exist only for s, t > 1 and are only used then; slot 0 is read otherwise)
     ConnVertex vl, ve;
     loadConn(L, s - 1, i, vl);
-    loadConn(E, t - 1, i, ve);
+    loadConnEye(S, E, t - 1, i, ve);
     d3 lprev = L.ld3(F_POS, s > 1 ? s - 2 : 0, i);
     d3 eprev = E.ld3(F_POS, t > 1 ? t - 2 : 0, i);
     WalkAhead wa;
@@ -580,12 +580,12 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
     {
         d3 ce = lpos - epos;
         ce = ce / sqrt(dot(ce, ce));
-        if ((dot(ce, E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, L.ld3(F_NG, s - 1, i)) <= 0)) return;
+        if ((dot(ce, t == 1 ? lensNormal(S) : E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, L.ld3(F_NG, s - 1, i)) <= 0)) return;
     }
     if (!visible<STATS>(S, lpos, epos, st, ty)) return;
     ConnVertex vl, ve;
     loadConn(L, s - 1, i, vl);
-    loadConn(E, t - 1, i, ve);
+    loadConnEye(S, E, t - 1, i, ve);
     d3 lprev = s > 1 ? L.ld3(F_POS, s - 2, i) : mk3(0, 0, 0);
     d3 eprev = t > 1 ? E.ld3(F_POS, t - 2, i) : mk3(0, 0, 0);
     WalkAhead wa;

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             lens.p_eye_A = 1.0 / S.lens_area;  // lens_area is 0 in the reference -> +inf
             lens.p_light_A = 0;
             lens.specular = false;
-            storeVertex(A.E, 0, i, lens);
+            storeLensVertex(A.E, i, lens);
             A.E.setMeta(i, 1);
             d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
             d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
