@@ -641,9 +641,12 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
         s_base = tot ? atomicAdd(A.pair_count, tot) : 0ULL;
     }
     __syncthreads();
+    unsigned long long wave_base = s_base;
+    for (uint32_t w = 0; w < (tid >> 6); w++) wave_base += s_wave[w];
+    // (Listing a wave's pairs in LDS first and writing its part of the queue with consecutive lanes on
+    // consecutive entries was measured: same kernel time, so every lane writes its own short run.)
     if (!cnt) return;
-    unsigned long long pos = s_base + (incl - cnt);
-    for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
+    unsigned long long pos = wave_base + (incl - cnt);
     if (pos + cnt <= A.pair_capacity) {
         // t-major: the t = 1 pairs (splats into other pixels) first, then every pair that lands in the
         // pixel-sample's own pixel next to each other, so that k_pair_eval can add them up before its atomics
