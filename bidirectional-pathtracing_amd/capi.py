@@ -102,6 +102,7 @@ EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
     "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
     "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
+    "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
@@ -161,6 +162,7 @@ def load_library(path=None):
     lib.ubdpt_request_stop.argtypes = [vp]
     lib.ubdpt_render_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum_slot.argtypes = [vp, C.c_uint32, vp, C.c_int]
+    lib.ubdpt_enqueue_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
     lib.ubdpt_upload_sum.argtypes = [vp, vp]
@@ -237,6 +239,12 @@ class Context:
         done = C.c_uint32(0)
         st = self.lib.ubdpt_render_passes_separate(self.handle, first_pass, n_passes, pass_stride, seed, C.byref(done))
         _check(st, "ubdpt_render_passes_separate", allow=(STOPPED,))
+        return st, done.value
+
+    def enqueue_passes_separate(self, first_pass, n_passes, seed, first_slot, pass_stride=1):
+        done = C.c_uint32(0)
+        st = self.lib.ubdpt_enqueue_passes_separate(self.handle, first_pass, n_passes, pass_stride, seed, first_slot, C.byref(done))
+        _check(st, "ubdpt_enqueue_passes_separate", allow=(STOPPED,))
         return st, done.value
 
     def read_sum_slot(self, slot, out=None, add_into=False):

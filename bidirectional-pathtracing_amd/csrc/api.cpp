@@ -110,6 +110,14 @@ struct ubdpt_context {
     uint64_t npix = 0;
     double* d_fb = nullptr;       // planar; the sum buffer, followed by pass_slots per-pass sum buffers
     uint32_t pass_slots = 0;      // > 0: ubdpt_render_passes_separate keeps up to that many passes apart
+    // ubdpt_enqueue_passes_separate: a fence is one event per lane, recorded behind the batches of a call; a per-pass
+    // buffer remembers the fence of the call that filled it last, and reading it waits for that fence only, not for
+    // passes enqueued later into other buffers. -1: filled by a call that waited itself.
+    static constexpr int kFences = 4;
+    std::vector<hipEvent_t> fences[kFences];
+    uint32_t next_fence = 0;
+    int slot_fence[64];
+    hipEvent_t clear_ev = nullptr;  // the per-pass buffers of a call have been cleared (the lanes wait for it)
     double* d_staging = nullptr;  // interleaved, npix * 3
     double* h_staging = nullptr;  // pinned host mirror of d_staging, allocated on first use (read-backs that add into the caller's buffer)
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
@@ -235,6 +243,8 @@ struct ubdpt_context {
             for (auto& f : b.inflight) hipEventDestroy(f.first);
         }
         for (auto& e : marker_pool) hipEventDestroy(e);
+        for (auto& f : fences) for (auto& e : f) hipEventDestroy(e);
+        if (clear_ev) hipEventDestroy(clear_ev);
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
@@ -529,6 +539,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
         }
         c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
+        for (int& f : c->slot_fence) f = -1;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix * (1 + c->pass_slots)));
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
@@ -601,19 +612,33 @@ static int finishPending(ubdpt_context* c) {
 }
 
 static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
-                        uint32_t* passes_done, bool wait, bool separate = false) {
+                        uint32_t* passes_done, bool wait, bool separate = false, uint32_t first_slot = 0) {
     if (passes_done) *passes_done = 0;
     if (!c) return UBDPT_INVALID_ARG;
-    if (separate && (c->pass_slots == 0 || n_passes > c->pass_slots)) return UBDPT_INVALID_ARG;
+    if (separate && (c->pass_slots == 0 || (uint64_t)first_slot + n_passes > c->pass_slots)) return UBDPT_INVALID_ARG;
     if (pass_stride == 0) pass_stride = 1;
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     c->stop = false;  // UBDPTRenderer::renderPass resets m_stop (ubdptrenderer.cpp:37)
     if (separate) {   // the per-pass buffers of this call start from zero
-        int fs = finishPending(c);
-        if (fs != UBDPT_SUCCESS) return fs;
-        HIPCK(c, hipMemsetAsync(c->d_fb + 3 * c->npix, 0, sizeof(double) * 3 * c->npix * n_passes, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (wait) {
+            int fs = finishPending(c);
+            if (fs != UBDPT_SUCCESS) return fs;
+        }
+        // cleared on the copy stream, which is also the one that reads them back, so the clear follows every earlier
+        // read of these buffers; the lanes wait for the clear, not for each other's older batches. Batches of an earlier
+        // call that may still be adding into these buffers (nobody read them) are waited for first.
+        bool seen[ubdpt_context::kFences] = {false};
+        for (uint32_t s = first_slot; s < first_slot + n_passes; s++) {
+            int f = c->slot_fence[s];
+            if (f < 0 || seen[f]) continue;
+            seen[f] = true;
+            for (hipEvent_t ev : c->fences[f]) HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0));
+        }
+        HIPCK(c, hipMemsetAsync(c->d_fb + 3 * c->npix * (1 + (uint64_t)first_slot), 0, sizeof(double) * 3 * c->npix * n_passes, c->stream));
+        if (!c->clear_ev) HIPCK(c, hipEventCreateWithFlags(&c->clear_ev, hipEventDisableTiming));
+        HIPCK(c, hipEventRecord(c->clear_ev, c->stream));
+        for (auto& b : c->lanes) HIPCK(c, hipStreamWaitEvent(b.stream, c->clear_ev, 0));
     }
     if (!c->work_pending) { c->work_pending = true; c->pending_since = nowSeconds(); }
     bool stats = c->opt.collect_stats != 0;
@@ -634,8 +659,10 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.S = c->S;
         A.E = B.E; A.L = B.L;
         A.E.n = A.L.n = nbatch;
-        A.fb = c->d_fb;
-        A.fb_slots = separate ? c->pass_slots : 0;
+        // per-pass buffers: pass j of the call adds into buffer 1 + first_slot + j (the kernels see the sum buffers
+        // shifted by first_slot buffers and take j modulo the buffers that remain, which is j)
+        A.fb = c->d_fb + (separate ? 3 * c->npix * (uint64_t)first_slot : 0);
+        A.fb_slots = separate ? c->pass_slots - first_slot : 0;
         A.first_pass = first_pass;
         A.path_offset = pos;
         A.batch_pass0 = pos / c->npix;
@@ -737,6 +764,20 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
     c->stats.passes += done;
     c->stats.pixel_samples += (uint64_t)done * c->npix;
     if (passes_done) *passes_done = done;
+    if (separate) {
+        int fence = -1;
+        if (!wait) {  // one event per lane behind the batches of this call
+            fence = (int)(c->next_fence++ % ubdpt_context::kFences);
+            auto& ev = c->fences[fence];
+            while (ev.size() < c->lanes.size()) {
+                hipEvent_t e;
+                HIPCK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                ev.push_back(e);
+            }
+            for (size_t l = 0; l < c->lanes.size(); l++) HIPCK(c, hipEventRecord(ev[l], c->lanes[l].stream));
+        }
+        for (uint32_t s = first_slot; s < first_slot + n_passes; s++) c->slot_fence[s] = fence;
+    }
     if (wait) {
         int fs = finishPending(c);
         if (fs != UBDPT_SUCCESS) return fs;
@@ -757,6 +798,11 @@ int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passe
 int ubdpt_render_passes_separate(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride,
                                  uint64_t seed, uint32_t* passes_done) {
     return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_done, true, true);
+}
+
+int ubdpt_enqueue_passes_separate(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride,
+                                  uint64_t seed, uint32_t first_slot, uint32_t* passes_enqueued) {
+    return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_enqueued, false, true, first_slot);
 }
 
 int ubdpt_synchronize(ubdpt_context* c) {
@@ -787,7 +833,14 @@ int ubdpt_read_sum_device(ubdpt_context* c, double* device_rgb) {
 static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add_into) {
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
-    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
+    const int fence = (buffer >= 1 && c->work_pending) ? c->slot_fence[buffer - 1] : -1;
+    if (fence >= 0) {
+        // filled by ubdpt_enqueue_passes_separate: the copy stream waits for the batches of that call only
+        for (hipEvent_t ev : c->fences[fence]) HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0));
+    } else {
+        int fs_ = finishPending(c);
+        if (fs_ != UBDPT_SUCCESS) return fs_;
+    }
     launchInterleave(c->d_fb + (uint64_t)buffer * 3 * c->npix, c->npix, c->d_staging, c->stream);
     HIPCK(c, hipGetLastError());
     if (!add_into) {

@@ -24,36 +24,57 @@ bool HipRenderer::initialize(const RenderParameters& render_params, std::shared_
     ubdpt_scene_desc desc;
     std::memset(&desc, 0, sizeof(desc));
     if (!scene->flatten(desc)) { m_status = UBDPT_INVALID_SCENE; return false; }
-    // window of passes rendered at once for renderPass: about 4 M pixel-samples, at most 32 passes
+    // window of passes rendered at once for renderPass: about 4 M pixel-samples, at most 32 passes; two windows
+    // of per-pass buffers, so that the device renders one while the host consumes the other
     ubdpt_options opt = m_options;
     if (opt.pass_slots == 0) {
         const uint64_t npix = (uint64_t)render_params.img_res_x * render_params.img_res_y;
-        opt.pass_slots = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, npix ? (1ull << 22) / npix : 1));
+        opt.pass_slots = 2 * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, npix ? (1ull << 22) / npix : 1));
     }
-    m_window_slots = std::min<uint32_t>(opt.pass_slots, 64);
-    m_window_count = 0;
+    opt.pass_slots = std::min<uint32_t>(opt.pass_slots, 64);
+    m_two_windows = opt.pass_slots >= 2;
+    m_window_slots = m_two_windows ? opt.pass_slots / 2 : 1;
+    m_window = Window{};
+    m_next_window = Window{};
     m_status = ubdpt_create(&desc, &render_params, &opt, m_device, &m_ctx);
     return m_status == UBDPT_SUCCESS;
+}
+
+// passes first_pass .. first_pass + window - 1, each into its own device sum buffer of the given half; not waited for
+bool HipRenderer::enqueueWindow(Window& w, size_t first_pass, uint32_t half) {
+    w = Window{};
+    uint32_t done = 0;
+    m_status = ubdpt_enqueue_passes_separate(m_ctx, first_pass, m_window_slots, 1, m_seed, half * m_window_slots, &done);
+    if (m_status != UBDPT_SUCCESS || done == 0) return false;   // stopped: the engine drops the write buffer
+    w.first = first_pass; w.count = done; w.seed = m_seed; w.half = half;
+    return true;
 }
 
 bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t /*num_threads*/,
                              std::function<void(double)>& update_progress_callback) {
     if (!m_ctx || !pixel_buffer) { m_status = UBDPT_UNINITIALIZED; return false; }
     m_stop_requested = false;  // UBDPTRenderer::renderPass resets m_stop on entry (ubdptrenderer.cpp:37)
-    const bool in_window = m_window_count != 0 && m_window_seed == m_seed && curr_pass >= m_window_first &&
-                           curr_pass < m_window_first + m_window_count;
-    if (!in_window) {
-        // passes curr_pass .. curr_pass + slots - 1, each into its own device sum buffer
-        m_window_count = 0;
-        uint32_t done = 0;
-        m_status = ubdpt_render_passes_separate(m_ctx, curr_pass, m_window_slots, 1, m_seed, &done);
-        if (m_status != UBDPT_SUCCESS || done == 0) return false;   // stopped: the engine drops the write buffer
-        m_window_first = curr_pass; m_window_count = done; m_window_seed = m_seed;
+    if (!m_window.holds(curr_pass, m_seed)) {
+        if (m_next_window.holds(curr_pass, m_seed)) {
+            m_window = m_next_window;
+            m_next_window = Window{};
+        } else {
+            m_next_window = Window{};
+            if (!enqueueWindow(m_window, curr_pass, 0)) return false;
+        }
+        // the passes after this window go to the other half of the buffers right away
+        if (m_two_windows && m_window.count == m_window_slots)
+            enqueueWindow(m_next_window, m_window.first + m_window.count, m_window.half ^ 1u);
     }
-    // this pass is added to the caller's running sum
-    m_status = ubdpt_read_sum_slot(m_ctx, (uint32_t)(curr_pass - m_window_first), pixel_buffer->ptr(), 1);
+    // this pass is added to the caller's running sum (waits for the window the pass belongs to, not for the next one)
+    m_status = ubdpt_read_sum_slot(m_ctx, m_window.half * m_window_slots + (uint32_t)(curr_pass - m_window.first),
+                                   pixel_buffer->ptr(), 1);
     if (m_status != UBDPT_SUCCESS) return false;
-    if (m_stop_requested) { m_status = UBDPT_STOPPED; m_window_count = 0; return false; }  // stop() arrived during this call
+    if (m_stop_requested) {  // stop() arrived during this call
+        m_status = UBDPT_STOPPED;
+        m_window = Window{}; m_next_window = Window{};
+        return false;
+    }
     if (update_progress_callback != nullptr) {
         std::lock_guard<std::mutex> lock(m_progress_mutex);
         update_progress_callback(1.0);

@@ -267,6 +267,17 @@ int ubdpt_upload_sum(ubdpt_context* ctx, const double* rgb);
 int ubdpt_render_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
                                  uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
 int ubdpt_read_sum_slot(ubdpt_context* ctx, uint32_t slot, double* rgb, int add_into);
+/*
+ * The same, enqueued without waiting for the GPU, into per-pass buffers first_slot .. first_slot + n_passes - 1
+ * (first_slot + n_passes <= pass_slots), so that the device renders the next window of passes into one half of
+ * the buffers while the host consumes the other half (the reference's counterpart: the render loop on its own thread,
+ * uapp/appmanager.cpp:430 and :486, while the GUI thread converts the finished buffer, :104). ubdpt_read_sum_slot of a
+ * buffer filled by this call waits for the passes of THAT call only; errors of enqueued work are reported by
+ * ubdpt_synchronize. Re-using buffers whose passes were never read is allowed (the clear waits for them).
+ */
+int ubdpt_enqueue_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
+                                  uint64_t pass_stride, uint64_t seed, uint32_t first_slot,
+                                  uint32_t* passes_enqueued);
 
 /* UScene::intersectionPoint (uengine/uscene.cpp:41-66) for n rays, through the backend's accelerator. */
 int ubdpt_intersect_batch(ubdpt_context* ctx, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);

@@ -365,6 +365,46 @@ def test_separate_passes_equal_the_passes_rendered_alone(pipeline):
     assert np.allclose(sum(slots), window, rtol=1e-12, atol=1e-12)
 
 
+def test_enqueued_windows_in_two_halves_equal_the_waited_form():
+    """ubdpt_enqueue_passes_separate fills one half of the per-pass buffers while the other half is read: every
+    buffer must equal the same pass rendered by the waited form, also when a half is re-used for a third window
+    and when buffers whose passes were never read are enqueued again."""
+    scene = SCENES["C2"]()
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(48, 48)
+    opt = capi.Options()
+    opt.pass_slots = 6
+    with capi.Context(scene, params, opt) as ctx:
+        ref = {}
+        for first in (0, 3, 6, 20):
+            ctx.render_passes_separate(first, 3, SEED)
+            for k in range(3):
+                ref[first + k] = ctx.read_sum_slot(k)
+        ctx.render_passes(50, 1, SEED)
+        resident = ctx.read_sum()
+        got = {}
+        st, done = ctx.enqueue_passes_separate(0, 3, SEED, 0)
+        assert st == capi.SUCCESS and done == 3
+        ctx.enqueue_passes_separate(3, 3, SEED, 3)
+        for k in range(3):
+            got[k] = ctx.read_sum_slot(k)            # waits for the first window only
+        ctx.enqueue_passes_separate(6, 3, SEED, 0)   # first half again, while the second is still unread
+        for k in range(3):
+            got[3 + k] = ctx.read_sum_slot(3 + k)
+        ctx.enqueue_passes_separate(20, 3, SEED, 3)  # a jump; then the never-read first half is overwritten
+        ctx.enqueue_passes_separate(6, 3, SEED, 0)
+        for k in range(3):
+            got[20 + k] = ctx.read_sum_slot(3 + k)
+            got[6 + k] = ctx.read_sum_slot(k)
+        with pytest.raises(Exception):
+            ctx.enqueue_passes_separate(0, 3, SEED, 4)   # 4 + 3 > 6 buffers
+        ctx.synchronize()
+        assert np.array_equal(ctx.read_sum(), resident)  # the device sum proper is left alone
+    assert sorted(got) == sorted(ref)
+    for p in ref:
+        assert ref[p].sum() > 0 and np.allclose(got[p], ref[p], rtol=1e-12, atol=1e-12), p
+
+
 def test_full_size_headline_workload_properties(oracle_mod):
     """The benchmark configuration at its full size (C2, 512 x 512): too large for a path-by-path comparison in a
     test, so size-independent properties are checked. 64 passes in one call equal the even plus the odd passes
