@@ -85,6 +85,40 @@ def test_engine_pass_by_pass_equals_batched_and_abi():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pass_slots", [1, 4, 5])
+def test_engine_pass_by_pass_across_windows(pass_slots):
+    """renderPass is served from windows of passes rendered ahead (two windows of pass_slots / 2 passes, one window of
+    one pass when there is a single buffer): crossing several windows, a batched call in between and a new rendering
+    must give the passes the engine asked for, whatever the device rendered ahead."""
+    sc, params = c2(40, 40)
+    opt = capi.Options()
+    opt.pass_slots = pass_slots
+    with hostapi.Engine(sc, options=opt) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        for k in range(7):
+            assert eng.render_pass() == hostapi.USUCCESS and eng.curr_pass == k + 1
+        a7 = eng.sum()
+        assert eng.render_passes(2) == hostapi.USUCCESS           # passes 7, 8 on the device sum
+        for k in range(3):
+            assert eng.render_pass() == hostapi.USUCCESS          # 9, 10, 11: not what was rendered ahead (7 ..)
+        a12 = eng.sum()
+        assert eng.new_rendering(params) == hostapi.USUCCESS      # back to pass 0
+        assert eng.render_pass() == hostapi.USUCCESS and eng.curr_pass == 1
+        a1 = eng.sum()
+    with capi.Context(sc, params) as ctx:
+        ctx.render_passes(0, 1, SEED)
+        c1 = ctx.read_sum()
+        ctx.render_passes(1, 6, SEED)
+        c7 = ctx.read_sum()
+        ctx.render_passes(7, 5, SEED)
+        c12 = ctx.read_sum()
+    assert c1.sum() > 0
+    assert np.allclose(a1, c1, rtol=1e-12, atol=1e-13)
+    assert np.allclose(a7, c7, rtol=1e-12, atol=1e-13)
+    assert np.allclose(a12, c12, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.gpu
 def test_engine_save_load_resume(tmp_path):
     sc, params = c2(32, 32)
     path = str(tmp_path / "r.ur")
