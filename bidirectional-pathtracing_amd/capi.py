@@ -61,7 +61,7 @@ class Options(C.Structure):
                 ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32), ("dense_threshold", C.c_uint32),
                 ("wavefront_depth", C.c_uint32), ("streams", C.c_uint32), ("batch_pixel_samples", C.c_uint32),
                 ("shadow_ray_budget", C.c_uint32), ("closest_ray_budget", C.c_uint32),
-                ("pass_slots", C.c_uint32)]
+                ("pass_slots", C.c_uint32), ("traversal_stack_entries", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3)])

@@ -127,6 +127,7 @@ struct ubdpt_context {
     uint32_t trace_budget = 0xffffffffu;   // the same for the closest-hit rays of the subpaths
     uint32_t shadow_rounds = 2;           // 2 or 3: budget, (4 x budget,) unlimited; 3 measured no faster than 2
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
+    uint32_t ovf_cap = kOverflowStack;  // entries of it a lane may use
     unsigned long long pair_capacity = 0;
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
     // lanes, so the narrow late stages of one batch (deep bounces, tail) overlap the wide early
@@ -539,6 +540,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
         }
         c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
+        c->ovf_cap = c->opt.traversal_stack_entries ? std::min<uint32_t>(c->opt.traversal_stack_entries, kOverflowStack) : kOverflowStack;
         for (int& f : c->slot_fence) f = -1;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix * (1 + c->pass_slots)));
@@ -593,6 +595,16 @@ int ubdpt_destroy(ubdpt_context* c) {
     return UBDPT_SUCCESS;
 }
 
+// A ray whose traversal stack was full dropped a subtree: whatever was computed with it may miss a hit.
+// The call that finds the counter set fails; the counter is cleared so that the context stays usable.
+static int reportStackOverflows(ubdpt_context* c) {
+    if (!c->stack_overflows) return UBDPT_SUCCESS;
+    fprintf(stderr, "ubdpt: traversal stack overflow in %llu waves or rays; the result of this call is not valid\n",
+            (unsigned long long)c->stack_overflows);
+    c->stack_overflows = 0;
+    return UBDPT_ERROR;
+}
+
 // Waits for every enqueued batch, then folds the event timings and the device counters into the
 // statistics. Called with the context mutex held.
 static int finishPending(ubdpt_context* c) {
@@ -604,11 +616,7 @@ static int finishPending(ubdpt_context* c) {
     int fc = fetchCounters(c);
     if (fc != UBDPT_SUCCESS) return fc;
     c->stats.render_seconds += nowSeconds() - c->pending_since;
-    if (c->stack_overflows) {
-        fprintf(stderr, "ubdpt: traversal stack overflow on %llu rays\n", (unsigned long long)c->stack_overflows);
-        return UBDPT_ERROR;
-    }
-    return UBDPT_SUCCESS;
+    return reportStackOverflows(c);
 }
 
 static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
@@ -669,7 +677,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.batch_pixel0 = pos % c->npix;
         A.pass_stride = pass_stride;
         A.seed = seed;
-        A.ovf = B.d_ovf; A.ovf_stride = A.E.n;
+        A.ovf = B.d_ovf; A.ovf_stride = A.E.n; A.ovf_cap = c->ovf_cap; A.pad_ovf = 0;
         A.counters = c->d_counters;
         A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
         A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
@@ -944,7 +952,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
         hipError_t e = hipMemcpyAsync(d_rays, rays + off, sizeof(ubdpt_ray) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_INTERSECT, (double)k);
-            launchIntersectBatch(c->S, d_rays, k, d_hits, c->lanes[0].d_ovf, k, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
+            launchIntersectBatch(c->S, d_rays, k, d_hits, c->lanes[0].d_ovf, k, c->ovf_cap, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -955,7 +963,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
     hipFree(d_rays); hipFree(d_hits);
     c->collectTimed();
     if (st == UBDPT_SUCCESS) st = fetchCounters(c);
-    if (st == UBDPT_SUCCESS && c->stack_overflows) return UBDPT_ERROR;
+    if (st == UBDPT_SUCCESS) st = reportStackOverflows(c);
     return st;
 }
 
@@ -977,7 +985,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
         hipError_t e = hipMemcpyAsync(d_segs, segs + off, sizeof(ubdpt_segment) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_VISIBILITY, (double)k);
-            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->lanes[0].d_ovf, k, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
+            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->lanes[0].d_ovf, k, c->ovf_cap, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -988,7 +996,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
     hipFree(d_segs); hipFree(d_vis);
     c->collectTimed();
     if (st == UBDPT_SUCCESS) st = fetchCounters(c);
-    if (st == UBDPT_SUCCESS && c->stack_overflows) return UBDPT_ERROR;
+    if (st == UBDPT_SUCCESS) st = reportStackOverflows(c);
     return st;
 }
 

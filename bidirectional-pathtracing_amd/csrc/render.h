@@ -19,6 +19,8 @@ struct RenderArgs {
     uint64_t batch_pixel0; // (batch_pixel0 + i), a number that almost always fits 32 bits, instead of a 64-bit index
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
     uint64_t ovf_stride;
+    uint32_t ovf_cap;      // entries of that overflow a lane may use (ubdpt_options.traversal_stack_entries)
+    uint32_t pad_ovf;
     unsigned long long* counters;
     uint64_t* pairs;                  // connection queue: (path << 16) | (s << 8) | t
     unsigned long long pair_capacity;
@@ -61,9 +63,9 @@ void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool stats, hipStream_t s);
 void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
-                          uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);
+                          uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
-                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s);
+                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);

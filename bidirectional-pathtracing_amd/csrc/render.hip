@@ -6,6 +6,8 @@
 // part of the path id), results are added to a planar fp64 sum buffer with hardware f64 atomics.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "paths.h"
 #include "render.h"
 
@@ -23,13 +25,14 @@ struct Tally {
     TraceCounters tc{0, 0, 0, 0};
 };
 
-DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid) {
+DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid, uint32_t ovf_cap) {
     Stack st;
     st.lds = lds_base + threadIdx.x;
     st.lds_stride = kBlock;
     st.ovf = ovf + gid;
     st.ovf_stride = ovf_stride;
     st.sp = 0;
+    st.cap = kLdsStack + (int)(ovf_cap < (uint32_t)kOverflowStack ? ovf_cap : (uint32_t)kOverflowStack);
     st.overflowed = false;
     return st;
 }
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
     uint32_t px, py;
     decodePath(A, gid, pass, pixel, px, py);
     Rng rng{pathKey(A.seed, pass, pixel), STREAM_EYE};
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
 
@@ -300,7 +303,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
     uint32_t px, py;
     decodePath(A, gid, pass, pixel, px, py);
     Rng rng{pathKey(A.seed, pass, pixel), STREAM_LIGHT};
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     uint32_t n = 0, smask = 0;
 
@@ -430,7 +433,7 @@ __global__ __launch_bounds__(kBlock) void k_connect(RenderArgs A) {
     uint64_t pass, pixel;
     uint32_t px, py;
     decodePath(A, gid, pass, pixel, px, py);
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
     uint32_t nE = E.cnt(gid), nL = L.cnt(gid);
@@ -661,7 +664,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
         // queue full: this lane evaluates its own pairs (slow path, same result); the part of its
         // reservation that lies inside the queue is filled with skip records (s == 0)
         for (unsigned long long j = pos; j < pos + cnt && j < A.pair_capacity; j++) A.pairs[j] = 0;
-        Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+        Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
         Tally ty;
         for (uint32_t s = 1; s <= nL; s++) {
             if (!L.connectable(mL, s - 1, gid)) continue;
@@ -682,7 +685,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_process(RenderArgs A) {
     uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
     unsigned long long total = *A.pair_count;
     if (total > A.pair_capacity) total = A.pair_capacity;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (unsigned long long j = gid; j < total; j += nthreads) {
         uint64_t p = A.pairs[j];
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(kBlock) void k_connect_hybrid(RenderArgs A, uint32_
     if (!queue_ok)  // queue full: skip records in the reserved part, the pairs are evaluated below
         for (unsigned long long j = pos; j < pos + cnt && j < A.pair_capacity; j++) A.pairs[j] = 0;
     // sweep 2: evaluate dense combinations, queue sparse ones
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (uint32_t s = 1; s <= maxL; s++) {
         bool hs = (okL >> (s - 1)) & 1;
@@ -785,47 +788,51 @@ namespace ub {
 // ---------------------------------------------------------------------------------------------------
 // probes: batch intersection / visibility / BSDF evaluation for parity checks
 // ---------------------------------------------------------------------------------------------------
+// Grid-stride: lane `gid` of the launch owns slice `gid` of the overflow stack and takes rays gid, gid + lanes, ...
+// (the ordinary entry point launches one lane per ray, the entry point that allocates nothing a fixed number of lanes).
 __global__ __launch_bounds__(kBlock) void k_intersect_batch(DScene S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits,
-                                                           int32_t* ovf, uint64_t ovf_stride,
+                                                           int32_t* ovf, uint64_t ovf_stride, uint32_t ovf_cap,
                                                            unsigned long long* counters) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
-    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid);
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t lanes = (uint64_t)gridDim.x * kBlock;
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid, ovf_cap);
     Tally ty;
-    Ray r;
-    r.o = mk3(rays[gid].origin[0], rays[gid].origin[1], rays[gid].origin[2]);
-    r.d = mk3(rays[gid].dir[0], rays[gid].dir[1], rays[gid].dir[2]);
-    Closest c = closestHit<true>(S, r, st, ty);
-    ubdpt_hit h;
-    if (c.object >= 0) {
-        SurfacePoint sp;
-        surfacePoint(S, r, c, sp);
-        h.hit = 1; h.object = c.object; h.face = c.face == kSphereFace ? -1 : (int64_t)c.face; h.d = c.d;
-        h.pos[0] = sp.pos.x; h.pos[1] = sp.pos.y; h.pos[2] = sp.pos.z;
-        h.Ng[0] = sp.Ng.x; h.Ng[1] = sp.Ng.y; h.Ng[2] = sp.Ng.z;
-        h.Ns[0] = sp.Ns.x; h.Ns[1] = sp.Ns.y; h.Ns[2] = sp.Ns.z;
-        h.Ts[0] = sp.Ts.x; h.Ts[1] = sp.Ts.y; h.Ts[2] = sp.Ts.z;
-        h.Bs[0] = sp.Bs.x; h.Bs[1] = sp.Bs.y; h.Bs[2] = sp.Bs.z;
-        h.tex_u = sp.tex_u; h.tex_v = sp.tex_v;
-    } else {
-        h.hit = 0; h.object = -1; h.face = -1; h.d = __builtin_inf();
-        for (int k = 0; k < 3; k++) h.pos[k] = h.Ng[k] = h.Ns[k] = h.Ts[k] = h.Bs[k] = 0;
-        h.tex_u = h.tex_v = 0;
+    for (uint64_t i = gid; i < n; i += lanes) {
+        Ray r;
+        r.o = mk3(rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]);
+        r.d = mk3(rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]);
+        Closest c = closestHit<true>(S, r, st, ty);
+        ubdpt_hit h;
+        if (c.object >= 0) {
+            SurfacePoint sp;
+            surfacePoint(S, r, c, sp);
+            h.hit = 1; h.object = c.object; h.face = c.face == kSphereFace ? -1 : (int64_t)c.face; h.d = c.d;
+            h.pos[0] = sp.pos.x; h.pos[1] = sp.pos.y; h.pos[2] = sp.pos.z;
+            h.Ng[0] = sp.Ng.x; h.Ng[1] = sp.Ng.y; h.Ng[2] = sp.Ng.z;
+            h.Ns[0] = sp.Ns.x; h.Ns[1] = sp.Ns.y; h.Ns[2] = sp.Ns.z;
+            h.Ts[0] = sp.Ts.x; h.Ts[1] = sp.Ts.y; h.Ts[2] = sp.Ts.z;
+            h.Bs[0] = sp.Bs.x; h.Bs[1] = sp.Bs.y; h.Bs[2] = sp.Bs.z;
+            h.tex_u = sp.tex_u; h.tex_v = sp.tex_v;
+        } else {
+            h.hit = 0; h.object = -1; h.face = -1; h.d = __builtin_inf();
+            for (int k = 0; k < 3; k++) h.pos[k] = h.Ng[k] = h.Ns[k] = h.Ts[k] = h.Bs[k] = 0;
+            h.tex_u = h.tex_v = 0;
+        }
+        hits[i] = h;
     }
-    hits[gid] = h;
-    atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
-    atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    if (ty.tc.nodes) atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
+    if (ty.tc.prims) atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
     if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
 }
 
 __global__ __launch_bounds__(kBlock) void k_visibility_batch(DScene S, const ubdpt_segment* segs, size_t n,
-                                                            uint8_t* vis, int32_t* ovf, uint64_t ovf_stride,
+                                                            uint8_t* vis, int32_t* ovf, uint64_t ovf_stride, uint32_t ovf_cap,
                                                             unsigned long long* counters) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= n) return;
-    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid);
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid, ovf_cap);
     Tally ty;
     d3 p0 = mk3(segs[gid].p0[0], segs[gid].p0[1], segs[gid].p0[2]);
     d3 p1 = mk3(segs[gid].p1[0], segs[gid].p1[1], segs[gid].p1[2]);
@@ -983,14 +990,14 @@ void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStre
     else hipLaunchKernelGGL(k_pair_process<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
-                          uint64_t ovf_stride, unsigned long long* counters, hipStream_t s) {
+                          uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_intersect_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, rays, n, hits, ovf, ovf_stride, counters);
+    hipLaunchKernelGGL(k_intersect_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, rays, n, hits, ovf, ovf_stride, ovf_cap, counters);
 }
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
-                           uint64_t ovf_stride, unsigned long long* counters, hipStream_t s) {
+                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_visibility_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, counters);
+    hipLaunchKernelGGL(k_visibility_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, ovf_cap, counters);
 }
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s) {
     if (n == 0) return;
@@ -1006,5 +1013,6 @@ void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma
                     hipStream_t s) {
     hipLaunchKernelGGL(k_image_rgb, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, passes, gamma, fit, out);
 }
+
 
 }  // namespace ub

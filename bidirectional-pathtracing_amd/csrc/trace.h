@@ -183,10 +183,11 @@ struct Stack {
     uint32_t lds_stride;
     uint64_t ovf_stride;
     int sp;
-    bool overflowed;
+    int cap;            // kLdsStack + the HBM entries this lane may use (at most kOverflowStack)
+    bool overflowed;    // a push found the stack full: the subtree was dropped, the result is not to be trusted
     DEV void push(int32_t v) {
         if (sp < kLdsStack) lds[sp * lds_stride] = v;
-        else if (sp < kLdsStack + kOverflowStack) ovf[(uint64_t)(sp - kLdsStack) * ovf_stride] = v;
+        else if (sp < cap) ovf[(uint64_t)(sp - kLdsStack) * ovf_stride] = v;
         else { overflowed = true; return; }
         sp++;
     }
@@ -235,7 +236,7 @@ DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, St
 // then false is returned and `best` holds the closest candidate found up to there. Calling again
 // with that `best` (the walk restarts at the root, pruned by best.d) gives the same final answer as
 // one unlimited call: the result is the lexicographic minimum over all primitives, whatever the order.
-DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack st, TraceCounters* tc, uint32_t budget, Closest& best) {
+DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc, uint32_t budget, Closest& best) {
     if (S.num_prims == 0) return true;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
@@ -258,7 +259,7 @@ DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack st, TraceCount
     }
     return true;
 }
-DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack st, TraceCounters* tc) {
+DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc) {
     Closest best;
     best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
     closestHitBvhBudget(S, r, st, tc, 0xffffffffu, best);
@@ -271,7 +272,7 @@ DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack st, TraceCounters
 // the rays that exceeded it again, together, keeps far more lanes busy in both rounds. The answer
 // does not depend on the order the tree is walked in, so a second run from the root is exact.
 enum { kBlocked = 0, kVisible = 1, kOutOfBudget = 2 };
-DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters* tc, uint32_t budget) {
+DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc, uint32_t budget) {
     double dist = length(p1 - p0);
     Ray r;
     r.o = p0;
@@ -299,7 +300,7 @@ DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters*
 }
 
 // UScene::visibility through the LBVH: true when nothing blocks p0 -> p1.
-DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack st, TraceCounters* tc) {
+DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc) {
     return visibleBvhBudget(S, p0, p1, st, tc, 0xffffffffu) == kVisible;
 }
 

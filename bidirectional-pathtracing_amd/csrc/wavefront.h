@@ -319,7 +319,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t dep
     const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * 2 * N;
     uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
     uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * 2 * N;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
         if (tid <= kWfRegions) s_cnt[tid] = 0;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A0, uint32_t dept
     uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
     uint32_t total = A.wf_count[(uint64_t)depth * kWfQStride];
     const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * 2 * N;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (uint64_t j = gid; j < total; j += nthreads) {
         uint32_t id = q[j];

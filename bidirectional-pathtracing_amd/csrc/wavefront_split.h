@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
     const uint64_t total = !first ? (uint64_t)*defer_cnt : depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
     const uint32_t* q = first ? A.wf_trace_q + (uint64_t)(depth & 1) * n2 : A.wf_defer_q;
     uint32_t* hit_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 1;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
         uint64_t j = base + tid;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_pair_visible(
     unsigned long long total = first ? *A.pair_count : (unsigned long long)*prev_n;
     if (total > A.pair_capacity) total = A.pair_capacity;
     const uint64_t* queue = first ? A.pairs : prev_q;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid);
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
     for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
         unsigned long long j = base + tid;

@@ -135,6 +135,9 @@ typedef struct ubdpt_options {
                                     candidate and is finished in a second launch); 0 -> default, 0xffffffff -> off */
     uint32_t pass_slots;        /* per-pass sum buffers held on the device besides the sum buffer (0: none, max 64);
                                    ubdpt_render_passes_separate keeps up to that many passes of a call apart */
+    uint32_t traversal_stack_entries; /* entries of a ray's traversal stack beyond the 12 kept on chip; 0 -> 96 (the
+                                   maximum). A ray that needs more makes the call that traced it return UBDPT_ERROR:
+                                   a dropped subtree could hide a hit, so such a result is never handed out silently */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */

@@ -553,3 +553,58 @@ def test_relmse_gate_against_independent_reference_seeds(oracle_mod, name):
     assert rel_mse(gpu, ref1) <= 1.5 * noise
     m_gpu, m_ref = gpu.reshape(-1, 3).mean(0), 0.5 * (ref1 + ref2).reshape(-1, 3).mean(0)
     assert np.all(np.abs(m_gpu - m_ref) / m_ref < 0.01)
+
+
+def stacked_triangles_scene(n=4096):
+    """n large triangles stacked 1e-4 apart along z: a ray along z meets every box of the tree on its way down,
+    so the traversal stack grows by three entries per four-wide level."""
+    b = scenes.SceneBuilder(scenes.make_camera((0, 0, -3.4), (0, 0, 0), 0.69, 1.0))
+    grey = b.color((0.7, 0.7, 0.7))
+    z = (np.arange(n) * 1e-4)[:, None]
+    tri = np.zeros((n, 3), capi.MESH_VERTEX_DTYPE)
+    tri["pos"][:, 0] = np.concatenate([np.full((n, 1), -0.8), np.full((n, 1), -0.5), z], 1)
+    tri["pos"][:, 1] = np.concatenate([np.full((n, 1), 0.8), np.full((n, 1), -0.5), z], 1)
+    tri["pos"][:, 2] = np.concatenate([np.full((n, 1), 0.0), np.full((n, 1), 0.9), z], 1)
+    tri["normal"] = (0, 0, -1)
+    tri["tangent"] = (1, 0, 0)
+    b.mesh(tri.reshape(-1), scenes.identity(), capi.MAT_LATEX_PAINT, grey)
+    b.mesh(scenes.quad((-.25, .999, -.25), (-.25, .999, .25), (.25, .999, .25), (.25, .999, -.25), (0, -1, 0), (1, 0, 0)),
+           scenes.identity(), capi.MAT_LATEX_PAINT, grey, power=(20, 20, 20))
+    return b.build()
+
+
+def test_traversal_stack_overflow_is_reported_not_hidden():
+    """A ray whose traversal stack is full would drop a subtree and could miss a hit. With the stack cut to
+    12 + 1 entries the stacked-triangle scene overflows it: every entry point that traced such a ray must return
+    UBDPT_ERROR. With the default stack the same scene renders and the tree agrees with the linear scan."""
+    scene = stacked_triangles_scene()
+    params = scenes.make_params(32, 32)
+    rays = np.zeros(256, capi.RAY_DTYPE)
+    rays["origin"] = (0.0, 0.0, -1.0)
+    rays["origin"][:, 0] = np.linspace(-0.2, 0.2, 256)
+    rays["dir"] = (0.0, 0.0, 1.0)
+    segs = np.zeros(256, capi.SEGMENT_DTYPE)
+    segs["p0"] = rays["origin"]
+    segs["p1"] = rays["origin"] + np.array((0.3, 0.2, 0.99))  # ends in front of the first triangle: nothing blocks
+    opt = capi.Options()
+    opt.traversal_stack_entries = 1
+    with capi.Context(scene, params, opt) as ctx:
+        with pytest.raises(capi.UbdptError) as e:
+            ctx.intersect_batch(rays)
+        assert e.value.status == capi.ERROR
+        with pytest.raises(capi.UbdptError) as e:
+            ctx.render_passes(0, 1, SEED)
+        assert e.value.status == capi.ERROR
+        # the failure is reported once; a call that overflows nothing succeeds again on the same context
+        assert ctx.visibility_batch(segs).all()
+    res = []
+    for accel in (0, 1):
+        opt = capi.Options()
+        opt.accel = accel
+        with capi.Context(scene, params, opt) as ctx:
+            res.append(ctx.intersect_batch(rays))
+            if accel == 0:
+                st, done = ctx.render_passes(0, 1, SEED)
+                assert st == capi.SUCCESS and done == 1
+    assert np.array_equal(res[0]["face"], res[1]["face"]) and (res[0]["face"] == 0).all()
+    assert np.array_equal(res[0]["d"].view(np.uint64), res[1]["d"].view(np.uint64))
