@@ -78,7 +78,7 @@ class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 40), ("launches", C.c_uint64), ("ms", C.c_double), ("units", C.c_double),
                 ("closest_hit_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
                 ("prims_tested", C.c_uint64), ("vertices", C.c_uint64), ("fb_updates", C.c_uint64),
-                ("wave_node_steps", C.c_uint64), ("wave_prim_steps", C.c_uint64)]
+                ("wave_node_steps", C.c_uint64), ("wave_prim_steps", C.c_uint64), ("max_stack_entries", C.c_uint64)]
 
 
 class Stats(C.Structure):

@@ -127,7 +127,7 @@ struct ubdpt_context {
     uint32_t trace_budget = 0xffffffffu;   // the same for the closest-hit rays of the subpaths
     uint32_t shadow_rounds = 2;           // 2 or 3: budget, (4 x budget,) unlimited; 3 measured no faster than 2
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
-    uint32_t ovf_cap = kOverflowStack;  // entries of it a lane may use
+    uint32_t ovf_cap = kLdsStack + kOverflowStack;  // entries of a lane's whole traversal stack (on-chip part included)
     unsigned long long pair_capacity = 0;
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
     // lanes, so the narrow late stages of one batch (deep bounces, tail) overlap the wide early
@@ -431,7 +431,10 @@ int fetchCounters(ubdpt_context* c) {
     HIPCK(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < K_NUM; k++) {
         const unsigned long long* h = hk[k];
-        for (int j = 0; j < kNumCounters; j++) c->kernel_counters[k][j] += h[j];
+        for (int j = 0; j < kNumCounters; j++) {
+            if (j == 13) c->kernel_counters[k][j] = std::max(c->kernel_counters[k][j], h[j]);  // C_MAX_STACK is a maximum
+            else c->kernel_counters[k][j] += h[j];
+        }
         if (k <= kLastRenderKernel) {  // the probe kernels do not count as rendering work
             c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
             c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
@@ -540,7 +543,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
         }
         c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
-        c->ovf_cap = c->opt.traversal_stack_entries ? std::min<uint32_t>(c->opt.traversal_stack_entries, kOverflowStack) : kOverflowStack;
+        c->ovf_cap = c->opt.traversal_stack_entries ? std::min<uint32_t>(c->opt.traversal_stack_entries, kLdsStack + kOverflowStack) : kLdsStack + kOverflowStack;
         for (int& f : c->slot_fence) f = -1;
         auto ck = [&](hipError_t e) { if (e != hipSuccess && st == UBDPT_SUCCESS) { c->last_hip = e; st = UBDPT_HIP_ERROR; } };
         ck(hipMalloc((void**)&c->d_fb, sizeof(double) * 3 * c->npix * (1 + c->pass_slots)));
@@ -1055,7 +1058,7 @@ int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
         ks.launches = c->kernel_launches[k]; ks.ms = c->kernel_ms[k]; ks.units = c->kernel_units[k];
         const unsigned long long* h = c->kernel_counters[k];
         ks.closest_hit_rays = h[0]; ks.shadow_rays = h[1]; ks.nodes_visited = h[6]; ks.prims_tested = h[7];
-        ks.wave_node_steps = h[11]; ks.wave_prim_steps = h[12];
+        ks.wave_node_steps = h[11]; ks.wave_prim_steps = h[12]; ks.max_stack_entries = h[13];
         ks.vertices = h[2] + h[3]; ks.fb_updates = h[10];
     }
     return UBDPT_SUCCESS;

@@ -19,7 +19,7 @@ struct RenderArgs {
     uint64_t batch_pixel0; // (batch_pixel0 + i), a number that almost always fits 32 bits, instead of a 64-bit index
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
     uint64_t ovf_stride;
-    uint32_t ovf_cap;      // entries of that overflow a lane may use (ubdpt_options.traversal_stack_entries)
+    uint32_t ovf_cap;      // entries of a lane's whole stack, on-chip part included (ubdpt_options.traversal_stack_entries)
     uint32_t pad_ovf;
     unsigned long long* counters;
     uint64_t* pairs;                  // connection queue: (path << 16) | (s << 8) | t

@@ -17,22 +17,22 @@ constexpr int kBlock = 256;
 
 // counters, indices into RenderArgs::counters
 enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB,
-       C_WAVE_NODES, C_WAVE_PRIMS, C_NUM };
+       C_WAVE_NODES, C_WAVE_PRIMS, C_MAX_STACK, C_NUM };
 static_assert(C_NUM <= kNumCounters, "counter block too small");
 
 struct Tally {
     uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0, fb = 0;
-    TraceCounters tc{0, 0, 0, 0};
+    TraceCounters tc{0, 0, 0, 0, 0};
 };
 
-DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid, uint32_t ovf_cap) {
+DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64_t gid, uint32_t stack_cap) {
     Stack st;
     st.lds = lds_base + threadIdx.x;
     st.lds_stride = kBlock;
     st.ovf = ovf + gid;
     st.ovf_stride = ovf_stride;
     st.sp = 0;
-    st.cap = kLdsStack + (int)(ovf_cap < (uint32_t)kOverflowStack ? ovf_cap : (uint32_t)kOverflowStack);
+    st.cap = (int)(stack_cap < (uint32_t)(kLdsStack + kOverflowStack) ? stack_cap : (uint32_t)(kLdsStack + kOverflowStack));
     st.overflowed = false;
     return st;
 }
@@ -67,6 +67,7 @@ DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_
     atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
     if (ty.tc.wave_nodes) atomicAdd(&counters[C_WAVE_NODES], (unsigned long long)ty.tc.wave_nodes);
     if (ty.tc.wave_prims) atomicAdd(&counters[C_WAVE_PRIMS], (unsigned long long)ty.tc.wave_prims);
+    if (ty.tc.max_stack) atomicMax(&counters[C_MAX_STACK], (unsigned long long)ty.tc.max_stack);
     atomicAdd(&counters[C_CAPPED], (unsigned long long)ty.capped);
     atomicAdd(&counters[C_FB], (unsigned long long)ty.fb);
     atomicAdd(&counters[C_EYE_V], (unsigned long long)eye_v);
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect_batch(DScene S, const ubdp
     }
     if (ty.tc.nodes) atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
     if (ty.tc.prims) atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    if (ty.tc.max_stack) atomicMax(&counters[C_MAX_STACK], (unsigned long long)ty.tc.max_stack);
     if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
 }
 

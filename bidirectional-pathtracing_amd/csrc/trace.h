@@ -74,6 +74,7 @@ struct Closest {
 struct TraceCounters {
     uint32_t nodes, prims;            // per lane: node visits, primitive tests
     uint32_t wave_nodes, wave_prims;  // per wave: times the wave executed a node step / a primitive test
+    uint32_t max_stack;               // deepest traversal stack seen (entries)
 };
 // Counts one wave-level execution of the code it stands in: nodes / (64 * wave_nodes) is the SIMD
 // utilisation of the node step, prims / (64 * wave_prims) that of the primitive test.
@@ -183,10 +184,12 @@ struct Stack {
     uint32_t lds_stride;
     uint64_t ovf_stride;
     int sp;
-    int cap;            // kLdsStack + the HBM entries this lane may use (at most kOverflowStack)
+    int cap;            // entries this lane may use, at most kLdsStack + kOverflowStack
     bool overflowed;    // a push found the stack full: the subtree was dropped, the result is not to be trusted
     DEV void push(int32_t v) {
-        if (sp < kLdsStack) lds[sp * lds_stride] = v;
+        // (two separate stores: a store through a pointer selected between LDS and device memory does not compile)
+        const int lim = cap < kLdsStack ? cap : kLdsStack;
+        if (sp < lim) lds[sp * lds_stride] = v;
         else if (sp < cap) ovf[(uint64_t)(sp - kLdsStack) * ovf_stride] = v;
         else { overflowed = true; return; }
         sp++;
@@ -224,6 +227,7 @@ DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, St
     if (t3 < inf) st.push(c3);
     if (t2 < inf) st.push(c2);
     if (t1 < inf) st.push(c1);
+    if (tc && (uint32_t)st.sp > tc->max_stack) tc->max_stack = (uint32_t)st.sp;
     if (t0 < inf) return c0;
     return st.sp ? st.pop() : kTraversalDone;
 }

@@ -135,8 +135,8 @@ typedef struct ubdpt_options {
                                     candidate and is finished in a second launch); 0 -> default, 0xffffffff -> off */
     uint32_t pass_slots;        /* per-pass sum buffers held on the device besides the sum buffer (0: none, max 64);
                                    ubdpt_render_passes_separate keeps up to that many passes of a call apart */
-    uint32_t traversal_stack_entries; /* entries of a ray's traversal stack beyond the 12 kept on chip; 0 -> 96 (the
-                                   maximum). A ray that needs more makes the call that traced it return UBDPT_ERROR:
+    uint32_t traversal_stack_entries; /* entries of a ray's traversal stack; 0 -> 108 (the maximum: 12 on chip, 96 in
+                                   device memory). A ray that needs more makes the call that traced it return UBDPT_ERROR:
                                    a dropped subtree could hide a hit, so such a result is never handed out silently */
 } ubdpt_options;
 
@@ -173,6 +173,7 @@ typedef struct ubdpt_kernel_stat {
     /* wave-level executions of the node step / the primitive test: nodes_visited / (64 * wave_node_steps)
      * is the SIMD utilisation of the traversal */
     uint64_t wave_node_steps, wave_prim_steps;
+    uint64_t max_stack_entries;  /* deepest traversal stack any ray of this kernel needed (collect_stats / probe kernels) */
 } ubdpt_kernel_stat;
 
 typedef struct ubdpt_stats {

@@ -555,12 +555,12 @@ def test_relmse_gate_against_independent_reference_seeds(oracle_mod, name):
     assert np.all(np.abs(m_gpu - m_ref) / m_ref < 0.01)
 
 
-def stacked_triangles_scene(n=4096):
-    """n large triangles stacked 1e-4 apart along z: a ray along z meets every box of the tree on its way down,
+def stacked_triangles_scene(n=32768):
+    """n large triangles stacked 2e-5 apart along z: a ray along z meets every box of the tree on its way down,
     so the traversal stack grows by three entries per four-wide level."""
     b = scenes.SceneBuilder(scenes.make_camera((0, 0, -3.4), (0, 0, 0), 0.69, 1.0))
     grey = b.color((0.7, 0.7, 0.7))
-    z = (np.arange(n) * 1e-4)[:, None]
+    z = (np.arange(n) * 2e-5)[:, None]
     tri = np.zeros((n, 3), capi.MESH_VERTEX_DTYPE)
     tri["pos"][:, 0] = np.concatenate([np.full((n, 1), -0.8), np.full((n, 1), -0.5), z], 1)
     tri["pos"][:, 1] = np.concatenate([np.full((n, 1), 0.8), np.full((n, 1), -0.5), z], 1)
@@ -575,7 +575,7 @@ def stacked_triangles_scene(n=4096):
 
 def test_traversal_stack_overflow_is_reported_not_hidden():
     """A ray whose traversal stack is full would drop a subtree and could miss a hit. With the stack cut to
-    12 + 1 entries the stacked-triangle scene overflows it: every entry point that traced such a ray must return
+    6 entries the stacked-triangle scene overflows it: every entry point that traced such a ray must return
     UBDPT_ERROR. With the default stack the same scene renders and the tree agrees with the linear scan."""
     scene = stacked_triangles_scene()
     params = scenes.make_params(32, 32)
@@ -587,7 +587,7 @@ def test_traversal_stack_overflow_is_reported_not_hidden():
     segs["p0"] = rays["origin"]
     segs["p1"] = rays["origin"] + np.array((0.3, 0.2, 0.99))  # ends in front of the first triangle: nothing blocks
     opt = capi.Options()
-    opt.traversal_stack_entries = 1
+    opt.traversal_stack_entries = 6
     with capi.Context(scene, params, opt) as ctx:
         with pytest.raises(capi.UbdptError) as e:
             ctx.intersect_batch(rays)

@@ -91,3 +91,66 @@ def load_golden(name):
     """npz fixture -> dict of arrays (no pickles inside)."""
     with np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
+
+
+class DeviceBuffer:
+    """Device memory for tests that hand DEVICE pointers to the C ABI, through the HIP runtime the backend library
+    itself is linked against (a second HIP runtime in the process, such as the one bundled with torch, cannot
+    initialise the GPU once this one has)."""
+    _hip = None
+
+    @classmethod
+    def hip(cls):
+        if cls._hip is None:
+            import ctypes as C
+            capi.load_library()  # maps libamdhip64 by its soname first
+            lib = None
+            for name in ("libamdhip64.so.7", "/opt/rocm/lib/libamdhip64.so.7", "libamdhip64.so"):
+                try:
+                    lib = C.CDLL(name)
+                    break
+                except OSError:
+                    continue
+            if lib is None:
+                raise RuntimeError("HIP runtime library not found")
+            lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            lib.hipFree.argtypes = [C.c_void_p]
+            lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            lib.hipDeviceSynchronize.argtypes = []
+            cls._hip = lib
+        return cls._hip
+
+    def __init__(self, nbytes, fill=None):
+        import ctypes as C
+        self.nbytes = max(1, int(nbytes))
+        self.ptr = C.c_void_p()
+        if self.hip().hipMalloc(C.byref(self.ptr), self.nbytes) != 0:
+            raise RuntimeError("hipMalloc failed")
+        if fill is not None:
+            self.hip().hipMemset(self.ptr, fill, self.nbytes)
+            self.hip().hipDeviceSynchronize()
+
+    def upload(self, array):
+        a = np.ascontiguousarray(array)
+        assert a.nbytes <= self.nbytes
+        if a.nbytes and self.hip().hipMemcpy(self.ptr, a.ctypes.data, a.nbytes, 1) != 0:  # hipMemcpyHostToDevice
+            raise RuntimeError("hipMemcpy H2D failed")
+        return self
+
+    def download(self, dtype, count):
+        out = np.zeros(count, dtype)
+        if out.nbytes and self.hip().hipMemcpy(out.ctypes.data, self.ptr, out.nbytes, 2) != 0:  # hipMemcpyDeviceToHost
+            raise RuntimeError("hipMemcpy D2H failed")
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.hip().hipFree(self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.free()
