@@ -20,6 +20,7 @@ MAT_LATEX_PAINT, MAT_GLOSSY, MAT_PERFECT_MIRROR, MAT_DIELECTRIC = 0, 1, 2, 3
 TEX_COLOR, TEX_IMAGE = 0, 1
 LOBE_NONE, LOBE_LAMBERTIAN, LOBE_MIRROR, LOBE_DIELECTRIC = -1, 0, 1, 2
 MAX_KERNEL_STATS = 24
+NOALLOC_MAX_RAYS = 1 << 20
 
 
 class Camera(C.Structure):
@@ -103,7 +104,7 @@ EXPORTS = [
     "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
     "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
     "ubdpt_enqueue_passes_separate",
-    "ubdpt_intersect_batch", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
+    "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
 ]
@@ -168,6 +169,7 @@ def load_library(path=None):
     lib.ubdpt_upload_sum.argtypes = [vp, vp]
     lib.ubdpt_image_rgb.argtypes = [vp, C.c_uint64, C.c_double, vp]
     lib.ubdpt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
+    lib.ubdpt_intersect_batch_noalloc.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ubdpt_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ubdpt_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     lib.ubdpt_get_camera_info.argtypes = [vp, vp, vp, vp]
@@ -297,6 +299,11 @@ class Context:
         _check(self.lib.ubdpt_intersect_batch(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data),
                "ubdpt_intersect_batch")
         return hits
+
+    def intersect_batch_noalloc(self, device_rays_ptr, n, device_hits_ptr):
+        """rays / hits: addresses of device buffers of RAY_DTYPE / HIT_DTYPE records (the caller's memory)."""
+        _check(self.lib.ubdpt_intersect_batch_noalloc(self.handle, device_rays_ptr, n, device_hits_ptr),
+               "ubdpt_intersect_batch_noalloc")
 
     def visibility_batch(self, segs):
         segs = np.ascontiguousarray(segs, SEGMENT_DTYPE)

@@ -128,6 +128,8 @@ struct ubdpt_context {
     uint32_t shadow_rounds = 2;           // 2 or 3: budget, (4 x budget,) unlimited; 3 measured no faster than 2
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
     uint32_t ovf_cap = kLdsStack + kOverflowStack;  // entries of a lane's whole traversal stack (on-chip part included)
+    void* noalloc_scratch = nullptr;             // device address of the static scratch array on this context's GPU
+    unsigned long long* h_noalloc_counters = nullptr;  // pinned, kNumCounters words: counters of the last no-allocation call
     unsigned long long pair_capacity = 0;
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
     // lanes, so the narrow late stages of one batch (deep bounces, tail) overlap the wide early
@@ -250,6 +252,7 @@ struct ubdpt_context {
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         if (h_staging) { hipHostFree(h_staging); h_staging = nullptr; }
+        if (h_noalloc_counters) { hipHostFree(h_noalloc_counters); h_noalloc_counters = nullptr; }
         for (auto& b : lanes) {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
@@ -576,6 +579,10 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
         }
         if (st != UBDPT_SUCCESS) break;
+        // set-up of the entry point that allocates nothing: this GPU's address of the static scratch array (asked for with
+        // this GPU current) and a pinned word block its counters are copied to
+        ck(noAllocScratch(device, &c->noalloc_scratch));
+        ck(hipHostMalloc((void**)&c->h_noalloc_counters, sizeof(unsigned long long) * kNumCounters, hipHostMallocDefault));
         ck(hipMalloc((void**)&c->d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
@@ -968,6 +975,28 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
     if (st == UBDPT_SUCCESS) st = fetchCounters(c);
     if (st == UBDPT_SUCCESS) st = reportStackOverflows(c);
     return st;
+}
+
+int ubdpt_intersect_batch_noalloc(ubdpt_context* c, const ubdpt_ray* device_rays, size_t n, ubdpt_hit* device_hits) {
+    if (!c || (n && (!device_rays || !device_hits))) return UBDPT_INVALID_ARG;
+    if (n > UBDPT_NOALLOC_MAX_RAYS) {
+        fprintf(stderr, "ubdpt_intersect_batch_noalloc: %zu rays exceed the limit of %llu rays per call\n", n,
+                (unsigned long long)UBDPT_NOALLOC_MAX_RAYS);
+        return UBDPT_INVALID_ARG;
+    }
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    if (c->work_pending) return UBDPT_ERROR;  // finishing enqueued passes folds statistics (host allocations): synchronize first
+    if (n == 0) return UBDPT_SUCCESS;
+    if (!c->noalloc_scratch || !c->h_noalloc_counters) return UBDPT_UNINITIALIZED;
+    HIPCK(c, launchIntersectBatchNoAlloc(c->S, device_rays, n, device_hits, c->noalloc_scratch, c->ovf_cap,
+                                         c->h_noalloc_counters, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (c->h_noalloc_counters[9]) {  // C_STACK_OVERFLOW
+        fprintf(stderr, "ubdpt_intersect_batch_noalloc: traversal stack overflow; the result of this call is not valid\n");
+        return UBDPT_ERROR;
+    }
+    return UBDPT_SUCCESS;
 }
 
 int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n, uint8_t* visible) {

@@ -66,6 +66,12 @@ void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdp
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
                            uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
+// The entry point that allocates nothing: a fixed number of lanes walk the ray batch with a stride; their
+// traversal-stack overflow and the counters live in a static device array (render.hip).
+constexpr uint64_t kNoAllocLanes = 32768;
+hipError_t noAllocScratch(int device, void** out);  // device must be current; resolves the array's address once per device
+hipError_t launchIntersectBatchNoAlloc(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, void* scratch_ptr,
+                                       uint32_t ovf_cap, unsigned long long* host_counters, hipStream_t s);
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);

@@ -1017,4 +1017,50 @@ void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Scratch memory of the entry point that allocates nothing (ubdpt_intersect_batch_noalloc): the overflow part of
+// the traversal stacks of kNoAllocLanes lanes, then kNumCounters counters. One copy per GPU, held until the process
+// ends; every call on a GPU uses that GPU's copy, so calls that overlap on one GPU race.
+// The array's name is only a host-side handle: its device address is asked for once per device and kept.
+// ---------------------------------------------------------------------------------------------------
+constexpr uint64_t kNoAllocStackBytes = sizeof(int32_t) * (uint64_t)kOverflowStack * kNoAllocLanes;
+constexpr uint64_t kNoAllocBytes = kNoAllocStackBytes + sizeof(unsigned long long) * kNumCounters;
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+constexpr int kMaxScratchDevices = 64;
+static void* g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+
+hipError_t noAllocScratch(int device, void** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        int cur = -1;
+        hipError_t e = hipGetDevice(&cur);
+        if (e != hipSuccess) return e;
+        if (cur != device) return hipErrorInvalidDevice;  // the address belongs to the device that is current
+        void* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+// `scratch_ptr` = what noAllocScratch returned for the current device; rays and hits are device memory.
+// Enqueues: clear of the counters, the intersection kernel on kNoAllocLanes lanes, copy of the counters to
+// `host_counters` (pinned, kNumCounters words). Allocates nothing.
+hipError_t launchIntersectBatchNoAlloc(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, void* scratch_ptr,
+                                       uint32_t ovf_cap, unsigned long long* host_counters, hipStream_t s) {
+    int32_t* ovf = reinterpret_cast<int32_t*>(scratch_ptr);
+    unsigned long long* counters = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(scratch_ptr) + kNoAllocStackBytes);
+    hipError_t e = hipMemsetAsync(counters, 0, sizeof(unsigned long long) * kNumCounters, s);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(kNoAllocLanes / kBlock, (n + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, s, S, rays, n, hits, ovf, (uint64_t)kNoAllocLanes, ovf_cap, counters);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return hipMemcpyAsync(host_counters, counters, sizeof(unsigned long long) * kNumCounters, hipMemcpyDeviceToHost, s);
+}
+
 }  // namespace ub

@@ -285,6 +285,19 @@ int ubdpt_enqueue_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint3
 
 /* UScene::intersectionPoint (uengine/uscene.cpp:41-66) for n rays, through the backend's accelerator. */
 int ubdpt_intersect_batch(ubdpt_context* ctx, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);
+/*
+ * No counterpart in the reference. For callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc. The same query as ubdpt_intersect_batch, but rays and hits
+ * are DEVICE buffers of the caller, and what the kernel needs besides them (the off-chip part of the traversal
+ * stacks, the overflow counter) lives in a fixed array inside the library (12.6 MB per GPU, held until the process
+ * ends) instead of in allocated memory: the call makes no hipMalloc / hipFree and allocates nothing on the host.
+ * n may not exceed UBDPT_NOALLOC_MAX_RAYS (UBDPT_INVALID_ARG otherwise). Passes enqueued on the context must have
+ * been waited for (ubdpt_synchronize) before the call, UBDPT_ERROR otherwise; UBDPT_ERROR as well when a traversal stack
+ * overflowed. Every call on one GPU uses the same array, whatever the context: calls that overlap on one GPU race.
+ * The call returns when the hits are complete.
+ */
+#define UBDPT_NOALLOC_MAX_RAYS (1ull << 20)
+int ubdpt_intersect_batch_noalloc(ubdpt_context* ctx, const ubdpt_ray* device_rays, size_t n, ubdpt_hit* device_hits);
 /* UScene::visibility (uengine/uscene.cpp:21-39) for n point pairs: visible[i] = 1 / 0. */
 int ubdpt_visibility_batch(ubdpt_context* ctx, const ubdpt_segment* segs, size_t n, uint8_t* visible);
 
