@@ -26,6 +26,7 @@
 #include "oracle_api.h"
 #include "omath.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -214,7 +215,27 @@ struct PathVertex { /* UPathVertex, uengine/ubdptrenderer.h:9-24 */
 
 struct Counters {
     uint64_t pixel_samples = 0, closest = 0, shadow = 0, eye_v = 0, light_v = 0, conn = 0, splats = 0, capped = 0,
-             prims = 0;
+             prims = 0, nodes = 0;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* Mode B: a bounding-volume hierarchy per mesh. NOT in the reference, which tests every face  */
+/* of a mesh for every ray (uapp/mesh.cpp:123-137, :170-180): at the sizes of the mesh          */
+/* workloads that scan is not runnable, so the CPU baseline for them walks this tree instead.   */
+/* The tree only decides WHICH faces are tested; every test is the reference's                  */
+/* intersectTriangle on the same object-local ray, and the winner is the lexicographic minimum  */
+/* of (d, face index), which is what the scan's strict '<' in face order selects. Boxes are     */
+/* padded far beyond the rounding of the triangle test, so no face the scan accepts is skipped  */
+/* (asserted against the scan on fixed ray batches by the tests).                               */
+/* ------------------------------------------------------------------------------------------ */
+struct BvhNode { /* 64 bytes: box, then either two children (count == 0: left, left + 1) or a run of faces */
+    double lo[3], hi[3];
+    uint32_t left_or_first, count;
+    uint64_t pad;
+};
+struct MeshBvh {
+    std::vector<BvhNode> nodes;
+    std::vector<uint32_t> faces; /* face indices inside the mesh, leaf order */
 };
 
 } // namespace
@@ -234,6 +255,221 @@ struct oracle_scene {
     dmat4 V, invV;
     const double m_W = 1.0;
     uint32_t max_path_vertices;
+    int accel = 0;                /* 0: the reference's scans; 1: Mode B, a tree per mesh */
+    std::vector<MeshBvh> bvh;     /* per object; empty for spheres and until Mode B is asked for */
+
+    /* ---- Mode B build: binned surface-area split, leaves of at most 4 faces ---- */
+    void buildMeshBvh(int oi) {
+        const Object& o = objects[oi];
+        MeshBvh& B = bvh[oi];
+        const size_t n = o.num_faces;
+        B.faces.resize(n);
+        std::vector<double> flo(3 * n), fhi(3 * n), cen(3 * n);
+        double mlo[3] = {1e300, 1e300, 1e300}, mhi[3] = {-1e300, -1e300, -1e300};
+        for (size_t f = 0; f < n; f++) {
+            B.faces[f] = (uint32_t)f;
+            const MeshVertex* fv = &verts[3 * (o.first_face + f)];
+            for (int k = 0; k < 3; k++) {
+                double a = (&fv[0].pos.x)[k], b = (&fv[1].pos.x)[k], c = (&fv[2].pos.x)[k];
+                flo[3 * f + k] = std::min(a, std::min(b, c));
+                fhi[3 * f + k] = std::max(a, std::max(b, c));
+                cen[3 * f + k] = 0.5 * (flo[3 * f + k] + fhi[3 * f + k]);
+                mlo[k] = std::min(mlo[k], flo[3 * f + k]);
+                mhi[k] = std::max(mhi[k], fhi[3 * f + k]);
+            }
+        }
+        /* padding: 1e-7 of the mesh size, many orders above the rounding of intersectTriangle */
+        const double pad = 1e-7 * std::max(mhi[0] - mlo[0], std::max(mhi[1] - mlo[1], mhi[2] - mlo[2])) + 1e-30;
+        B.nodes.clear();
+        B.nodes.reserve(n);
+        B.nodes.push_back(BvhNode{});
+        struct Job { uint32_t node, first, count; };
+        std::vector<Job> jobs{{0, 0, (uint32_t)n}};
+        constexpr int kBins = 16;
+        while (!jobs.empty()) {
+            Job j = jobs.back();
+            jobs.pop_back();
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            double clo[3] = {1e300, 1e300, 1e300}, chi[3] = {-1e300, -1e300, -1e300};
+            for (uint32_t i = j.first; i < j.first + j.count; i++) {
+                uint32_t f = B.faces[i];
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = std::min(lo[k], flo[3 * f + k]); hi[k] = std::max(hi[k], fhi[3 * f + k]);
+                    clo[k] = std::min(clo[k], cen[3 * f + k]); chi[k] = std::max(chi[k], cen[3 * f + k]);
+                }
+            }
+            BvhNode nd{};
+            for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k] - pad; nd.hi[k] = hi[k] + pad; }
+            int axis = 0;
+            if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
+            if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
+            const double ext = chi[axis] - clo[axis];
+            if (j.count <= 4 || !(ext > 0)) { /* leaf (also: all centres coincide) */
+                nd.left_or_first = j.first; nd.count = j.count;
+                B.nodes[j.node] = nd;
+                continue;
+            }
+            /* bins along the axis of the widest centroid extent; cost = area(left) * n(left) + area(right) * n(right) */
+            uint32_t bc[kBins] = {0};
+            double blo[kBins][3], bhi[kBins][3];
+            for (int b = 0; b < kBins; b++) for (int k = 0; k < 3; k++) { blo[b][k] = 1e300; bhi[b][k] = -1e300; }
+            const double scale = (double)kBins * (1.0 - 1e-9) / ext;
+            for (uint32_t i = j.first; i < j.first + j.count; i++) {
+                uint32_t f = B.faces[i];
+                int b = (int)((cen[3 * f + axis] - clo[axis]) * scale);
+                bc[b]++;
+                for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], flo[3 * f + k]); bhi[b][k] = std::max(bhi[b][k], fhi[3 * f + k]); }
+            }
+            auto area = [](const double* l, const double* h) {
+                double x = h[0] - l[0], y = h[1] - l[1], z = h[2] - l[2];
+                return (x < 0 || y < 0 || z < 0) ? 0.0 : 2.0 * (x * y + y * z + z * x);
+            };
+            double la[kBins], ra[kBins];
+            uint32_t ln[kBins], rn[kBins];
+            {
+                double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+                uint32_t c = 0;
+                for (int b = 0; b < kBins; b++) {
+                    c += bc[b];
+                    for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); }
+                    la[b] = area(l, h); ln[b] = c;
+                }
+                double l2[3] = {1e300, 1e300, 1e300}, h2[3] = {-1e300, -1e300, -1e300};
+                c = 0;
+                for (int b = kBins - 1; b >= 0; b--) {
+                    c += bc[b];
+                    for (int k = 0; k < 3; k++) { l2[k] = std::min(l2[k], blo[b][k]); h2[k] = std::max(h2[k], bhi[b][k]); }
+                    ra[b] = area(l2, h2); rn[b] = c;
+                }
+            }
+            int best = -1;
+            double best_cost = 1e300;
+            for (int b = 0; b + 1 < kBins; b++) {
+                if (ln[b] == 0 || rn[b + 1] == 0) continue;
+                double cost = la[b] * ln[b] + ra[b + 1] * rn[b + 1];
+                if (cost < best_cost) { best_cost = cost; best = b; }
+            }
+            uint32_t mid;
+            if (best < 0) mid = j.first + j.count / 2; /* everything in one bin: split the run in the middle */
+            else {
+                uint32_t* beg = B.faces.data() + j.first;
+                uint32_t* m = std::partition(beg, beg + j.count, [&](uint32_t f) {
+                    return (int)((cen[3 * f + axis] - clo[axis]) * scale) <= best;
+                });
+                mid = (uint32_t)(m - B.faces.data());
+            }
+            nd.left_or_first = (uint32_t)B.nodes.size(); nd.count = 0;
+            B.nodes[j.node] = nd;
+            B.nodes.push_back(BvhNode{});
+            B.nodes.push_back(BvhNode{});
+            jobs.push_back({nd.left_or_first, j.first, mid - j.first});
+            jobs.push_back({nd.left_or_first + 1, mid, j.first + j.count - mid});
+        }
+    }
+    void setAccel(int mode) {
+        accel = mode;
+        if (mode == 1 && bvh.empty()) {
+            bvh.resize(objects.size());
+            for (int o = 0; o < (int)objects.size(); o++)
+                if (objects[o].kind == UBDPT_MODEL_MESH) buildMeshBvh(o);
+        }
+    }
+    /* entry and exit parameter of the ray through a padded box; the interval is widened by 1e-12 relative */
+    static bool slab(const BvhNode& n, const double o[3], const double inv[3], double tmax, double& tnear) {
+        double t0 = -std::numeric_limits<double>::infinity(), t1 = std::numeric_limits<double>::infinity();
+        for (int k = 0; k < 3; k++) {
+            double a = (n.lo[k] - o[k]) * inv[k], b = (n.hi[k] - o[k]) * inv[k];
+            if (a != a || b != b) continue; /* 0 * inf: the origin lies on a plane of a slab the ray is parallel to */
+            if (a > b) { double t = a; a = b; b = t; }
+            if (a > t0) t0 = a;
+            if (b < t1) t1 = b;
+        }
+        t0 -= std::fabs(t0) * 1e-12;
+        t1 += std::fabs(t1) * 1e-12;
+        tnear = t0;
+        return t0 <= t1 && t1 >= 0 && t0 <= tmax;
+    }
+    /* Closest face of mesh `o` for the local ray: lexicographic minimum of (d, face). Returns false when no face is hit. */
+    bool bvhClosestFace(int oi, const Ray& rayL, double& ci_d, double& ci_u, double& ci_v, size_t& ci_face, Counters* cn) const {
+        const Object& o = objects[oi];
+        const MeshBvh& B = bvh[oi];
+        const dvec3 ro = rayL.origin(), rd = rayL.dir();
+        const double org[3] = {ro.x, ro.y, ro.z};
+        const double inv[3] = {1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z};
+        const double inf = std::numeric_limits<double>::infinity();
+        ci_d = inf; ci_u = ci_v = 0; ci_face = 0;
+        bool hit = false;
+        uint32_t stack[128];
+        int sp = 0;
+        double tn;
+        if (cn) cn->nodes++;
+        if (!slab(B.nodes[0], org, inv, inf, tn)) return false;
+        uint32_t node = 0;
+        for (;;) {
+            const BvhNode& n = B.nodes[node];
+            if (n.count) {
+                for (uint32_t i = n.left_or_first; i < n.left_or_first + n.count; i++) {
+                    const uint32_t f = B.faces[i];
+                    const MeshVertex* face = &verts[3 * (o.first_face + f)];
+                    double d, u, v;
+                    if (cn) cn->prims++;
+                    if (intersectTriangle(rayL, face[0].pos, face[1].pos, face[2].pos, d, u, v))
+                        if (d < ci_d || (d == ci_d && f < ci_face)) { ci_d = d; ci_u = u; ci_v = v; ci_face = f; hit = true; }
+                }
+            } else {
+                double ta, tb;
+                const uint32_t a = n.left_or_first, b = a + 1;
+                if (cn) cn->nodes += 2;
+                const bool ha = slab(B.nodes[a], org, inv, ci_d, ta), hb = slab(B.nodes[b], org, inv, ci_d, tb);
+                if (ha && hb) {
+                    if (sp >= 126) return hit; /* cannot happen: depth is bounded by the face count's logarithm times a constant */
+                    if (ta <= tb) { stack[sp++] = b; node = a; } else { stack[sp++] = a; node = b; }
+                    continue;
+                }
+                if (ha) { node = a; continue; }
+                if (hb) { node = b; continue; }
+            }
+            /* pop; a box entered behind the best hit so far cannot hold a smaller (d, face) */
+            for (;;) {
+                if (sp == 0) return hit;
+                node = stack[--sp];
+                if (cn) cn->nodes++;
+                if (slab(B.nodes[node], org, inv, ci_d, tn)) break;
+            }
+        }
+    }
+    /* Does any face of mesh `o` block the local ray before `dist`? (mesh.cpp:170-187 finds the smallest d of all
+     * accepted faces; it is below dist exactly when some accepted face's d is, and accepted faces have d > 0.) */
+    bool bvhMinBelow(int oi, const Ray& rayL, double dist, double& min_d, Counters* cn) const {
+        const Object& o = objects[oi];
+        const MeshBvh& B = bvh[oi];
+        const dvec3 ro = rayL.origin(), rd = rayL.dir();
+        const double org[3] = {ro.x, ro.y, ro.z};
+        const double inv[3] = {1.0 / rd.x, 1.0 / rd.y, 1.0 / rd.z};
+        uint32_t stack[128];
+        int sp = 0;
+        double tn;
+        if (cn) cn->nodes++;
+        if (!slab(B.nodes[0], org, inv, dist, tn)) return false;
+        stack[sp++] = 0;
+        while (sp) {
+            const BvhNode& n = B.nodes[stack[--sp]];
+            if (n.count) {
+                for (uint32_t i = n.left_or_first; i < n.left_or_first + n.count; i++) {
+                    const MeshVertex* face = &verts[3 * (o.first_face + B.faces[i])];
+                    double d, u, v;
+                    if (cn) cn->prims++;
+                    if (intersectTriangle(rayL, face[0].pos, face[1].pos, face[2].pos, d, u, v) && d < dist) { min_d = d; return true; }
+                }
+            } else {
+                const uint32_t a = n.left_or_first;
+                if (cn) cn->nodes += 2;
+                if (sp < 126 && slab(B.nodes[a], org, inv, dist, tn)) stack[sp++] = a;
+                if (sp < 126 && slab(B.nodes[a + 1], org, inv, dist, tn)) stack[sp++] = a + 1;
+            }
+        }
+        return false;
+    }
 
     /* --- uapp/mesh.cpp:38-86 --- */
     dmat4 computeBoundingSphere(size_t first, size_t n) const {
@@ -306,6 +542,8 @@ struct oracle_scene {
         double d, u, v;
         bool hit = false;
         if (!intersectUnitSphere(rayL.transform(o.bounding_sphere), d)) return false;
+        if (accel == 1) hit = bvhClosestFace((int)(&o - objects.data()), rayL, ci_d, ci_u, ci_v, ci_face, cn); /* Mode B */
+        else
         for (size_t f = 0; f < o.num_faces; f++) {
             const MeshVertex* face = &verts[3 * (o.first_face + f)];
             if (cn) cn->prims++;
@@ -342,6 +580,15 @@ struct oracle_scene {
         }
         if (hit) { d = min_d; return true; }
         return false;
+    }
+    /* Mode B form of Object::intersects for UScene::visibility: does the object block the ray before `dist`? */
+    bool objectBlocks(int oi, const Ray& ray, double dist, Counters* cn) const {
+        const Object& o = objects[oi];
+        double d;
+        if (o.kind == UBDPT_MODEL_SPHERE || accel != 1) return objectIntersects(oi, ray, d, cn) && (d < dist) && (d > 0);
+        Ray rayL = ray.transform(o.invW);
+        if (!intersectUnitSphere(rayL.transform(o.bounding_sphere), d)) return false;
+        return bvhMinBelow(oi, rayL, dist, d, cn);
     }
     /* --- uapp/object.cpp:14-25 (the lobe is drawn later, for the closest hit only) --- */
     bool objectIntersectionPoint(int oi, const Ray& ray, SurfacePoint& sp, double& d, Counters* cn) const {
@@ -389,6 +636,11 @@ struct oracle_scene {
         double points_distance = length(p1 - p0);
         Ray ray(p0, (p1 - p0) / points_distance);
         if (cn) cn->shadow++;
+        if (accel == 1) {
+            for (int o = 0; o < (int)objects.size(); o++)
+                if (objectBlocks(o, ray, points_distance, cn)) return false;
+            return true;
+        }
         for (int o = 0; o < (int)objects.size(); o++) {
             if (objectIntersects(o, ray, d, cn)) {
                 if ((d < points_distance) && (d > 0)) return false;
@@ -1164,6 +1416,12 @@ int oracle_create(const ubdpt_scene_desc* sd, const ubdpt_render_params* rp, uin
 
 void oracle_destroy(oracle_scene* s) { delete s; }
 
+int oracle_set_accel(oracle_scene* s, int mode) {
+    if (!s || (mode != 0 && mode != 1)) return UBDPT_INVALID_ARG;
+    s->setAccel(mode);
+    return UBDPT_SUCCESS;
+}
+
 int oracle_render_passes(oracle_scene* S, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
                          int num_threads, double* rgb, oracle_counters* counters) {
     if (!S || !rgb) return UBDPT_INVALID_ARG;
@@ -1204,7 +1462,7 @@ int oracle_render_passes(oracle_scene* S, uint64_t first_pass, uint32_t n_passes
         for (auto& k : cns) {
             c.pixel_samples += k.pixel_samples; c.closest_hit_rays += k.closest; c.shadow_rays += k.shadow;
             c.eye_vertices += k.eye_v; c.light_vertices += k.light_v; c.connections += k.conn; c.splats += k.splats;
-            c.capped_subpaths += k.capped; c.prims_tested += k.prims;
+            c.capped_subpaths += k.capped; c.prims_tested += k.prims; c.nodes_visited += k.nodes;
         }
         *counters = c;
     }

@@ -35,6 +35,7 @@ typedef struct oracle_counters {
     uint64_t splats;             /* t == 1 contributions */
     uint64_t capped_subpaths;
     uint64_t prims_tested;       /* sphere + triangle tests in closest-hit and shadow scans */
+    uint64_t nodes_visited;      /* box tests of the per-mesh trees (Mode B only) */
 } oracle_counters;
 
 /* One stored path vertex, world space (UPathVertex, uengine/ubdptrenderer.h:9-24). */
@@ -52,6 +53,13 @@ typedef struct oracle_vertex {
 int  oracle_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* params,
                    uint32_t max_path_vertices, oracle_scene** out);
 void oracle_destroy(oracle_scene* s);
+
+/* mode 0 (default): the reference's scans over every object and every face (uengine/uscene.cpp:41-66,
+ * uapp/mesh.cpp:123-137). mode 1 ("Mode B"): the same object loop, but a mesh finds its closest / any blocking
+ * face through a bounding-volume hierarchy built here; not in the reference, needed because the scan is not
+ * runnable at 10^5..10^6 faces. Every hit is still decided by the reference's triangle test and tie rule, and the
+ * tests assert that both modes report the same hits. */
+int  oracle_set_accel(oracle_scene* s, int mode);
 
 /* Adds passes first_pass + i*pass_stride (i < n_passes) into rgb (H x W x 3, row-major [y][x][rgb]). */
 int  oracle_render_passes(oracle_scene* s, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride,

@@ -24,7 +24,7 @@ VERTEX_DTYPE = np.dtype([("pos", "<f8", 3), ("Ng", "<f8", 3), ("Ns", "<f8", 3), 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pixel_samples", "closest_hit_rays", "shadow_rays", "eye_vertices",
                                           "light_vertices", "connections", "splats", "capped_subpaths",
-                                          "prims_tested")]
+                                          "prims_tested", "nodes_visited")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -42,6 +42,7 @@ def lib():
         vp = C.c_void_p
         l.oracle_create.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.RenderParams), C.c_uint32, C.POINTER(vp)]
         l.oracle_destroy.argtypes = [vp]
+        l.oracle_set_accel.argtypes = [vp, C.c_int]
         l.oracle_destroy.restype = None
         l.oracle_render_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, vp,
                                            C.POINTER(Counters)]
@@ -72,6 +73,11 @@ class Oracle:
         st = self.lib.oracle_create(C.byref(scene.desc), C.byref(params), max_path_vertices, C.byref(self.handle))
         if st != 0:
             raise RuntimeError(f"oracle_create failed: {st}")
+
+    def set_accel(self, mode):
+        """0: the reference's linear scans (default); 1: Mode B, a bounding-volume hierarchy per mesh."""
+        assert self.lib.oracle_set_accel(self.handle, int(mode)) == 0
+        return self
 
     def close(self):
         if self.handle:
