@@ -215,7 +215,7 @@ struct PathVertex { /* UPathVertex, uengine/ubdptrenderer.h:9-24 */
 
 struct Counters {
     uint64_t pixel_samples = 0, closest = 0, shadow = 0, eye_v = 0, light_v = 0, conn = 0, splats = 0, capped = 0,
-             prims = 0, nodes = 0;
+             prims = 0, nodes = 0, prims_closest = 0, nodes_closest = 0;
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -617,6 +617,7 @@ struct oracle_scene {
         bool hit = false;
         double d;
         if (cn) cn->closest++;
+        const uint64_t prims0 = cn ? cn->prims : 0, nodes0 = cn ? cn->nodes : 0;
         for (int o = 0; o < (int)objects.size(); o++) {
             if (objectIntersectionPoint(o, ray, sp, d, cn)) {
                 if (d < min_d) {
@@ -627,6 +628,7 @@ struct oracle_scene {
                 }
             }
         }
+        if (cn) { cn->prims_closest += cn->prims - prims0; cn->nodes_closest += cn->nodes - nodes0; }
         if (out_d) *out_d = min_d;
         return hit;
     }
@@ -1463,6 +1465,7 @@ int oracle_render_passes(oracle_scene* S, uint64_t first_pass, uint32_t n_passes
             c.pixel_samples += k.pixel_samples; c.closest_hit_rays += k.closest; c.shadow_rays += k.shadow;
             c.eye_vertices += k.eye_v; c.light_vertices += k.light_v; c.connections += k.conn; c.splats += k.splats;
             c.capped_subpaths += k.capped; c.prims_tested += k.prims; c.nodes_visited += k.nodes;
+            c.prims_tested_closest += k.prims_closest; c.nodes_visited_closest += k.nodes_closest;
         }
         *counters = c;
     }

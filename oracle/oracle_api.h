@@ -36,6 +36,8 @@ typedef struct oracle_counters {
     uint64_t capped_subpaths;
     uint64_t prims_tested;       /* sphere + triangle tests in closest-hit and shadow scans */
     uint64_t nodes_visited;      /* box tests of the per-mesh trees (Mode B only) */
+    uint64_t prims_tested_closest; /* the part of prims_tested / nodes_visited spent on closest-hit rays */
+    uint64_t nodes_visited_closest;
 } oracle_counters;
 
 /* One stored path vertex, world space (UPathVertex, uengine/ubdptrenderer.h:9-24). */

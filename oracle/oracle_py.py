@@ -24,7 +24,8 @@ VERTEX_DTYPE = np.dtype([("pos", "<f8", 3), ("Ng", "<f8", 3), ("Ns", "<f8", 3), 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("pixel_samples", "closest_hit_rays", "shadow_rays", "eye_vertices",
                                           "light_vertices", "connections", "splats", "capped_subpaths",
-                                          "prims_tested", "nodes_visited")]
+                                          "prims_tested", "nodes_visited", "prims_tested_closest",
+                                          "nodes_visited_closest")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

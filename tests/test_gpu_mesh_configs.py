@@ -1,0 +1,137 @@
+"""The mesh workloads (BASELINE.json configs 3-5) through ubdpt_render_passes at their full triangle counts.
+
+C3: 100 k triangles, image texture, 1080p. C4: 2 M triangles, 1080p. C5: 100 k triangles, Lambertian / glossy /
+mirror / dielectric, 4K. The CPU oracle's scan over every face (the reference's algorithm, uapp/mesh.cpp:123-137)
+is not runnable at these sizes, so the full-size runs are checked through properties that do not depend on the
+size: the multi-GPU pass partition adds up, step budgets do not change the image, the tree agrees with the
+device's linear scan, the image mean agrees with the oracle's tree mode (Mode B, itself asserted equal to the
+scan by tests/test_oracle_bvh.py) at a resolution it finishes in seconds. The material mix of C5 is compared
+with the oracle path by path on a 6 k-triangle version of the same scene."""
+import functools
+
+import numpy as np
+import pytest
+
+from util import capi, rel_mse, scenes
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0x5EED
+
+
+@functools.lru_cache(maxsize=None)
+def config(name):
+    return scenes.make_config(name)
+
+
+def reduced(params, div):
+    return scenes.make_params(int(params.img_res_x) // div, int(params.img_res_y) // div)
+
+
+@pytest.mark.parametrize("name,passes", [("C3", 4), ("C4", 4), ("C5", 2)])
+def test_full_size_render_properties(name, passes):
+    """Full resolution, full triangle count: passes {0..n-1} in one call == even passes + odd passes (the
+    multi-GPU partition), every value finite and non-negative, the part of the image that shows the box is lit,
+    no traversal stack came near its limit, and the image mean agrees with the CPU oracle within 4 %."""
+    import oracle_py
+    scene, params, _ = config(name)
+    opt = capi.Options()
+    opt.collect_stats = 1
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        full = ctx.read_sum()
+        s = ctx.stats()
+        ctx.upload_sum(None)
+        ctx.render_passes(0, passes // 2, SEED, pass_stride=2)
+        ctx.render_passes(1, passes // 2, SEED, pass_stride=2)
+        halves = ctx.read_sum()
+    assert np.isfinite(full).all() and (full >= 0).all()
+    assert np.allclose(full, halves, rtol=1e-11, atol=1e-11)
+    H, W = full.shape[:2]
+    box = full[:, W // 2 - H // 4: W // 2 + H // 4]  # the camera sees the open box in the middle of the 16:9 image
+    assert (box.sum(axis=2) > 0).mean() > (0.95 if passes >= 4 else 0.9)  # two passes leave more of the dark corners unlit
+    assert s["pixel_samples"] == W * H * passes
+    assert 0 < max(k["max_stack_entries"] for k in s["kernels"]) <= 64
+    small = reduced(params, 20)
+    orc = oracle_py.Oracle(scene, small, 32).set_accel(1)
+    n_ref = 16
+    ref = orc.render_passes(0, n_ref, SEED + 1, num_threads=8)
+    m_gpu, m_ref = full.reshape(-1, 3).mean(0) / passes, ref.reshape(-1, 3).mean(0) / n_ref
+    assert np.all(np.abs(m_gpu - m_ref) <= 0.04 * m_ref), (m_gpu, m_ref)
+
+
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
+def test_step_budgets_do_not_change_the_image_at_full_triangle_count(name):
+    """Budgets of 2 steps (nearly every ray is finished in the second launch), the defaults and none: same image,
+    same counters. Full triangle count, an eighth of the resolution."""
+    scene, params, _ = config(name)
+    small = reduced(params, 8)
+    res = []
+    for shadow, closest in ((0xffffffff, 0xffffffff), (0, 0), (2, 2)):
+        opt = capi.Options()
+        opt.collect_stats = 1
+        opt.shadow_ray_budget = shadow
+        opt.closest_ray_budget = closest
+        with capi.Context(scene, small, opt) as ctx:
+            st, done = ctx.render_passes(0, 3, SEED)
+            assert st == capi.SUCCESS and done == 3
+            res.append((ctx.read_sum(), ctx.stats()))
+    img0, s0 = res[0]
+    assert img0.sum() > 0
+    for img, s in res[1:]:
+        assert np.allclose(img, img0, rtol=1e-12, atol=1e-12)
+        for k in ("closest_hit_rays", "shadow_rays", "eye_vertices", "light_vertices", "connections", "splats"):
+            assert s[k] == s0[k], k
+
+
+@pytest.mark.parametrize("name", ["C3", "C5"])
+def test_tree_image_equals_linear_scan_image(name):
+    """ubdpt_render_passes with the tree against the same call with accel = 1 (the device's linear scan in the
+    reference's order) at 100 k triangles: the same paths, hence the same image to rounding of the sums."""
+    scene, params, _ = config(name)
+    small = reduced(params, 30)
+    imgs = []
+    for accel in (0, 1):
+        opt = capi.Options()
+        opt.accel = accel
+        opt.collect_stats = 1
+        with capi.Context(scene, small, opt) as ctx:
+            st, done = ctx.render_passes(0, 2, SEED)
+            assert st == capi.SUCCESS and done == 2
+            imgs.append((ctx.read_sum(), ctx.stats()))
+    (a, sa), (b, sb) = imgs
+    assert a.sum() > 0 and np.allclose(a, b, rtol=1e-12, atol=1e-12)
+    for k in ("closest_hit_rays", "shadow_rays", "eye_vertices", "light_vertices", "connections", "splats"):
+        assert sa[k] == sb[k], k
+
+
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_mixed_material_mesh_scene_matches_oracle_path_by_path(pipeline):
+    """The material mix of C5 (Glossy on an image-textured mesh, a mirror torus mesh, a dielectric sphere;
+    uapp/material.h:17-104) on a 6 k-triangle version of the scene, against the oracle's scan, path by path:
+    at most 0.5 % of the pixels may deviate by more than 1e-9 relative."""
+    import oracle_py
+    w = h = 48
+    passes = 3
+    scene = scenes.mesh_scene(6000, seed=3, ratio=1.0, mixed=True)
+    params = scenes.make_params(w, h)
+    opt = capi.Options()
+    opt.collect_stats = 1
+    opt.pipeline = pipeline
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        got = ctx.read_sum()
+        s = ctx.stats()
+    ref, cn = oracle_py.Oracle(scene, params, 32).render_passes(0, passes, SEED, num_threads=8, counters=True)
+    assert np.array_equal(np.isfinite(got), np.isfinite(ref))
+    fin = np.isfinite(ref).all(axis=2)
+    g, r = np.where(fin[..., None], got, 0) / passes, np.where(fin[..., None], ref, 0) / passes
+    err = np.abs(g - r) / np.maximum(np.abs(r), 1e-3)
+    bad = float(np.any(err > 1e-9, axis=2).mean())
+    print(f"mixed mesh scene, pipeline {pipeline}: {bad * 100:.3f} % of pixels off by > 1e-9")
+    assert bad <= 0.005, bad
+    assert rel_mse(g, r) <= 2e-3
+    for k in ("eye_vertices", "light_vertices", "connections", "splats"):
+        assert abs(s[k] - cn[k]) <= 5e-3 * cn[k] + 2, (k, s[k], cn[k])

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 R=$PWD
 OUT=$R/$1; shift
 mkdir -p "$OUT"
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $*"
 run_pass() {
   name=$1; shift
   ( cd /tmp && timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 "$R/bench.py" $ARGS > "$OUT/$name.log" 2>&1 ) || return 1

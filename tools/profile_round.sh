@@ -11,7 +11,7 @@ T=$R/gpurun_out/$1; shift
 TAG=$(basename "$T")
 mkdir -p "$T"
 timeout -k 10 500 python3 bench.py "$@" > "$T/bench.json" 2> "$T/bench.err" || exit 1
-( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 "$R/bench.py" --no-cpu-baseline "$@" > "$T/bench_under_rocprof.json" 2> "$T/rocprof.err" ) || exit 2
+( cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$T/stats" -- python3 "$R/bench.py" --no-cpu-baseline --no-other-configs "$@" > "$T/bench_under_rocprof.json" 2> "$T/rocprof.err" ) || exit 2
 bash tools/pmc_passes.sh "gpurun_out/$TAG/pmc" "$@" || exit 3
 python3 tools/pmc_summary.py "$T/pmc" "$T/pmc/summary.json" || exit 4
 echo "profile round $TAG done"

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""Turns a PMC summary (tools/pmc_summary.py) into profiles/traffic.json: HBM bytes per launch of
-every rendering kernel (the non-counting instantiation, `<false>` or `<false, placement>`).
+"""Turns a PMC summary (tools/pmc_summary.py) into an entry of profiles/traffic.json: HBM bytes per launch of
+every rendering kernel (the non-counting instantiation, `<false>` or `<false, placement>`) for ONE configuration.
+
+  traffic_from_pmc.py <summary.json> <config> [profiles/traffic.json]
+
+The file maps configuration -> kernel -> bytes per launch; other configurations' entries are kept.
 
   bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024
 
@@ -14,8 +18,8 @@ import sys
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc/summary.json"
-    dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/traffic.json"
+    src, config = sys.argv[1], sys.argv[2]
+    dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
     d = json.load(open(src))
     out, detail = {}, {}
     for name, c in d.items():
@@ -30,7 +34,14 @@ def main():
                      "uncorrected_bytes_per_launch": (fetch_kib + write_kib) * 1024.0}
     out["_detail"] = detail
     out["_formula"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; FETCH doubled for gfx950 (upper bound for <=64-B requests)"
-    json.dump(out, open(dst, "w"), indent=1, sort_keys=True)
+    try:
+        allc = json.load(open(dst))
+        if not all(isinstance(v, dict) for v in allc.values()):
+            allc = {}
+    except Exception:
+        allc = {}
+    allc[config] = out
+    json.dump(allc, open(dst, "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items()):
         if not k.startswith("_"):
             print("%-20s %10.1f MB/launch" % (k, v / 1e6))
