@@ -273,10 +273,6 @@ def main():
     ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--batch-pixel-samples", type=int, default=0, help="sub-pass batches of this many pixels (0 = whole passes)")
-    ap.add_argument("--shadow-ray-budget", type=lambda x: int(x, 0), default=0,
-                    help="large scenes: traversal steps before a shadow ray is deferred to a second launch (0 = default, 0xffffffff = off)")
-    ap.add_argument("--closest-ray-budget", type=lambda x: int(x, 0), default=0,
-                    help="large scenes: the same for the closest-hit rays of the subpaths (0 = default, 0xffffffff = off)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -329,8 +325,6 @@ def main():
     opt.wavefront_depth = args.wavefront_depth
     opt.streams = args.streams
     opt.batch_pixel_samples = args.batch_pixel_samples
-    opt.shadow_ray_budget = args.shadow_ray_budget
-    opt.closest_ray_budget = args.closest_ray_budget
     ctx = capi.Context(scene, params, opt, device)
     sum_dev = torch.zeros((H, W, 3), dtype=torch.float64, device=f"cuda:{device}")
 

@@ -64,10 +64,10 @@ m4 boundingSphere(const ubdpt_mesh_vertex* verts, uint64_t first, uint64_t n) {
     return inverse(scale(translate(identity4(), center), mk3(radius, radius, radius)));
 }
 
-enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_CONNECT_HYBRID, K_PAIR_PROCESS, K_PAIR_VISIBLE,
-                K_PAIR_EVAL, K_WF_GEN, K_WF_BOUNCE, K_WF_TRACE, K_WF_SHADE, K_WF_TAIL, K_INTERSECT, K_VISIBILITY, K_NUM };
-const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_connect_hybrid",
-                                   "k_pair_process", "k_pair_visible", "k_pair_eval", "k_wf_gen", "k_wf_bounce", "k_wf_trace",
+enum KernelId { K_EYE = 0, K_LIGHT, K_CONNECT, K_PAIR_ENUM, K_PAIR_SETUP, K_RAYS_VISIBLE, K_PAIR_COMPACT,
+                K_PAIR_EVAL, K_WF_GEN, K_WF_TRACE, K_WF_SHADE, K_WF_TAIL, K_INTERSECT, K_VISIBILITY, K_NUM };
+const char* kKernelNames[K_NUM] = {"k_eye", "k_light", "k_connect", "k_pair_enum", "k_pair_setup", "k_rays_visible",
+                                   "k_pair_compact", "k_pair_eval", "k_wf_gen", "k_wf_trace",
                                    "k_wf_shade", "k_wf_tail", "k_intersect_batch", "k_visibility_batch"};
 constexpr int kLastRenderKernel = K_WF_TAIL;
 
@@ -123,9 +123,6 @@ struct ubdpt_context {
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
     uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
-    uint32_t shadow_budget = 0xffffffffu;  // traversal steps a shadow ray gets in the first round (0xffffffff: no second round)
-    uint32_t trace_budget = 0xffffffffu;   // the same for the closest-hit rays of the subpaths
-    uint32_t shadow_rounds = 2;           // 2 or 3: budget, (4 x budget,) unlimited; 3 measured no faster than 2
     uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
     uint32_t ovf_cap = kLdsStack + kOverflowStack;  // entries of a lane's whole traversal stack (on-chip part included)
     void* noalloc_scratch = nullptr;             // device address of the static scratch array on this context's GPU
@@ -142,12 +139,11 @@ struct ubdpt_context {
         unsigned long long* d_pair_count = nullptr;
         double* d_carry = nullptr;
         double* d_wf_hit = nullptr;
-        uint32_t* d_wf_hit_q = nullptr;
         uint64_t* d_vis_pairs = nullptr;
         uint32_t* d_vis_count = nullptr;
-        uint64_t* d_defer_pairs[2] = {nullptr, nullptr};  // allocated only when shadow rays get a step budget
-        uint32_t* d_defer_count = nullptr;                // two counters
-        uint32_t* d_wf_defer_q = nullptr;                 // allocated only when closest-hit rays get a step budget
+        double* d_rays = nullptr;        // shadow-ray queue (wavefront pipeline only)
+        uint32_t* d_ray_count = nullptr;  // [0] rays in the queue, [1] claim position of the persistent waves
+        uint8_t* d_ray_flag = nullptr;
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
@@ -257,7 +253,7 @@ struct ubdpt_context {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
             hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
-            hipFree(b.d_wf_hit_q); hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_defer_pairs[0]); hipFree(b.d_defer_pairs[1]); hipFree(b.d_defer_count); hipFree(b.d_wf_defer_q); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
+            hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
         }
         hipFree(d_counters);
@@ -498,7 +494,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
     double t0 = nowSeconds();
     c->device = device;
     if (options) c->opt = *options;
-    if (c->opt.pipeline > 3) { delete c; return UBDPT_INVALID_ARG; }
+    if (c->opt.pipeline > 1) { delete c; return UBDPT_INVALID_ARG; }
     if (c->opt.max_path_vertices == 0) c->opt.max_path_vertices = 32;
     if (c->opt.max_path_vertices < 2) c->opt.max_path_vertices = 2;
     if (c->opt.max_path_vertices > 255) c->opt.max_path_vertices = 255;
@@ -510,7 +506,9 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((st = flattenAndUpload(c, scene)) != UBDPT_SUCCESS) break;
         c->npix = params->img_res_x * params->img_res_y;
         // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
-        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8;
+        // (vertex records of both subpaths, overflow stack, pair / ray / visible-pair queues of 24 entries per path)
+        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8 +
+                            24ull * (8 + 8 + sizeof(double) * kRayDoubles + 1);
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
             uint64_t target = 1ull << 22;  // measured: throughput still rises up to ~4 M pixel-samples per batch
@@ -537,14 +535,6 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         }
         if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
         c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 8;
-        // a step budget for shadow rays pays where rays walk a tree in HBM; a scene that lives in LDS needs none
-        c->shadow_budget = 0xffffffffu;
-        c->trace_budget = 0xffffffffu;
-        if (c->opt.pipeline == 0 && c->S.accel == 0) {
-            const bool in_lds = sceneLdsLevel(c->S) == 2;  // default there: no budget (measured: no gain)
-            c->shadow_budget = c->opt.shadow_ray_budget ? c->opt.shadow_ray_budget : in_lds ? 0xffffffffu : kDefaultShadowBudget;
-            c->trace_budget = c->opt.closest_ray_budget ? c->opt.closest_ray_budget : in_lds ? 0xffffffffu : kDefaultClosestBudget;
-        }
         c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
         c->ovf_cap = c->opt.traversal_stack_entries ? std::min<uint32_t>(c->opt.traversal_stack_entries, kLdsStack + kOverflowStack) : kLdsStack + kOverflowStack;
         for (int& f : c->slot_fence) f = -1;
@@ -567,14 +557,13 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             ck(hipMalloc((void**)&b.d_pair_count, sizeof(unsigned long long)));
             ck(hipMalloc((void**)&b.d_carry, sizeof(double) * kCarryDoubles * n2));
             ck(hipMalloc((void**)&b.d_wf_hit, sizeof(double) * kHitDoubles * n2));
-            // every 256-chunk is padded to whole waves: at most 63 extra entries per chunk
-            ck(hipMalloc((void**)&b.d_wf_hit_q, sizeof(uint32_t) * (n2 + 64 * (n2 / 256 + 2))));
             ck(hipMalloc((void**)&b.d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
             ck(hipMalloc((void**)&b.d_vis_count, sizeof(uint32_t)));
-            ck(hipMalloc((void**)&b.d_defer_count, 2 * sizeof(uint32_t)));
-            if (c->shadow_budget != 0xffffffffu)
-                for (int k = 0; k < 2; k++) ck(hipMalloc((void**)&b.d_defer_pairs[k], sizeof(uint64_t) * c->pair_capacity));
-            if (c->trace_budget != 0xffffffffu) ck(hipMalloc((void**)&b.d_wf_defer_q, sizeof(uint32_t) * n2));
+            ck(hipMalloc((void**)&b.d_ray_count, 2 * sizeof(uint32_t)));
+            if (c->opt.pipeline == 0) {
+                ck(hipMalloc((void**)&b.d_rays, sizeof(double) * kRayDoubles * c->pair_capacity));
+                ck(hipMalloc((void**)&b.d_ray_flag, c->pair_capacity));
+            }
             ck(hipMalloc((void**)&b.d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
             ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
         }
@@ -691,22 +680,19 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.counters = c->d_counters;
         A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
         A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
-        A.wf_hit = B.d_wf_hit; A.wf_hit_q = B.d_wf_hit_q; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
-        for (int k = 0; k < 2; k++) { A.defer_pairs[k] = B.d_defer_pairs[k]; A.defer_count[k] = B.d_defer_count + k; }
-        A.wf_defer_q = B.d_wf_defer_q;
+        A.wf_hit = B.d_wf_hit; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
+        A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
         // grid-stride kernels; 512 .. 16384 workgroups measured within 2 % of each other
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
         uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
-        // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, visible, eval (default)
-        //           1 = per-path subpath kernels + per-path connection loop
-        //           2 = per-path subpath kernels + global pair queue, one kernel per pair
-        //           3 = wavefront with fused trace+shade bounce kernel + in-place dense / queued sparse pairs
+        // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, setup, rays, compact, eval (default)
+        //           1 = per-path subpath kernels + per-path connection loop (the reference's loop structure, kept as a cross-check)
         const uint32_t pl = c->opt.pipeline;
-        if (pl == 0 || pl == 3) {
-            // wavefront pipelines: the count word of subpath `id` is the eighth double of its carry record's first
-            // line (eye subpaths first, then the light subpaths), so trace and shade touch one line less per subpath
+        if (pl == 0) {
+            // the count word of subpath `id` is the eighth double of its carry record's first line (eye subpaths
+            // first, then the light subpaths), so trace and shade touch one line less per subpath
             const uint32_t stride = kCarryDoubles * (uint32_t)(sizeof(double) / sizeof(uint32_t));
             A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + kCarryCountSlot);
             A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + kCarryCountSlot);
@@ -717,57 +703,30 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.counters = c->d_counters + kernel * kNumCounters;
             c->beginTimedLane(B, kernel, u); launch(); c->endTimedLane(B);
         };
-        if (pl == 0 || pl == 3) {
+        if (pl == 0) {
             HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
             A.ovf_stride = pstride;
             run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
             for (uint32_t d = 0; d < D; d++) {
-                if (pl == 3) {
-                    run(K_WF_BOUNCE, d == 0 ? units : 0, [&] { launchWfBounce(A, d, pblocks, stats, sm); });
-                } else {
-                    run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, 0, c->trace_budget, pblocks, stats, sm); });
-                    if (c->trace_budget != 0xffffffffu)  // the rays that ran out of budget, together
-                        run(K_WF_TRACE, 0, [&] { launchWfTrace(A, d, 1, 0xffffffffu, pblocks, stats, sm); });
-                    run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
-                }
+                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, pblocks, stats, sm); });
+                run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
             }
             run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
+            HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
+            HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
+            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 2 * sizeof(uint32_t), sm));
+            A.ovf_stride = A.E.n;  // the enumeration runs one lane per pixel-sample (its slow path traces rays)
+            run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
+            A.ovf_stride = pstride;
+            run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
+            run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, pblocks, stats, sm); });
+            run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
+            run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
         } else {
             A.ovf_stride = A.E.n;
             run(K_EYE, units, [&] { launchEye(A, stats, sm); });
             run(K_LIGHT, units, [&] { launchLight(A, stats, sm); });
-        }
-        if (pl == 1) {
-            A.ovf_stride = A.E.n;
             run(K_CONNECT, units, [&] { launchConnect(A, stats, sm); });
-        } else {
-            HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
-            A.ovf_stride = A.E.n;
-            if (pl == 3) {
-                uint32_t thr = c->opt.dense_threshold ? c->opt.dense_threshold : 40;
-                run(K_CONNECT_HYBRID, units, [&] { launchConnectHybrid(A, thr, stats, sm); });
-            } else {
-                run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
-            }
-            A.ovf_stride = pstride;
-            if (pl == 0) {
-                HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
-                HIPCK(c, hipMemsetAsync(B.d_defer_count, 0, 2 * sizeof(uint32_t), sm));
-                if (c->shadow_budget == 0xffffffffu) {
-                    run(K_PAIR_VISIBLE, units, [&] { launchPairVisible(A, 0, 0xffffffffu, pblocks, stats, sm); });
-                } else {
-                    // rounds of growing budget; the rays that exceed one round's budget are traced again, together, in the next
-                    const uint32_t rounds = c->shadow_rounds;
-                    uint32_t budget = c->shadow_budget;
-                    for (uint32_t r = 0; r < rounds; r++, budget *= 4) {
-                        const uint32_t b = r + 1 == rounds ? 0xffffffffu : budget;
-                        run(K_PAIR_VISIBLE, r == 0 ? units : 0, [&] { launchPairVisible(A, r, b, pblocks, stats, sm); });
-                    }
-                }
-                run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
-            } else {
-                run(K_PAIR_PROCESS, units, [&] { launchPairProcess(A, pblocks, stats, sm); });
-            }
         }
         HIPCK(c, hipGetLastError());
         pos += nbatch;

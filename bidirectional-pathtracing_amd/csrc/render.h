@@ -28,30 +28,30 @@ struct RenderArgs {
     // wavefront subpath generation (wavefront.h); subpath id in [0, 2n)
     double* carry;           // [2n][kCarryDoubles]: the ray in flight and what the next bounce needs of the last two vertices
     double* wf_hit;          // [2n][kHitDoubles]: d, u, v, (object | face << 32) of the closest hit found by k_wf_trace
-    uint32_t* wf_hit_q;      // hit queue: id | region << 29, chunks padded to whole waves with 0xffffffff
     uint64_t* vis_pairs;     // connection pairs that passed the shadow ray
     uint32_t* vis_count;
-    uint64_t* defer_pairs[2];  // pairs whose shadow ray ran out of its step budget, written by round r to [r & 1] (null when no budget is used)
-    uint32_t* defer_count[2];
+    double* rays;            // shadow-ray queue, kRayDoubles per ray: origin, direction, length, the pair (bits)
+    uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at
+    uint32_t* ray_head;
+    uint8_t* ray_flag;       // one per ray: 1 = nothing blocks it
     uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
-    uint32_t* wf_count;      // [depth][16] queue lengths ([d][0] trace queue, [d][1] hit queue, [d][2] deferred rays), zeroed before every batch
-    uint32_t* wf_defer_q;    // [2n] ids of the rays of the current depth that ran out of their step budget (null when no budget is used)
+    uint32_t* wf_count;      // [depth][16]: [d][0] length of the depth's trace queue, [d][3] the position the persistent waves claim chunks at; zeroed before every batch
 };
 
 constexpr uint32_t kMaxWfDepth = 30;  // most bounces that can run as wavefront launches before the tail loop takes over
-constexpr int kWfQStride = 16;        // counters per depth: [0] trace queue length, [1] hit queue length
+constexpr int kWfQStride = 16;        // counters per depth
+constexpr int kRayDoubles = 8;        // one 64-byte line per shadow ray
 constexpr int kCarryDoubles = 16;     // two 64-byte lines per subpath
 constexpr int kCarryCountSlot = 7;    // the double of the first line that holds the subpath's count word
 constexpr int kHitDoubles = 4;        // half a line per subpath
-constexpr uint32_t kDefaultClosestBudget = 12; // the same for closest-hit rays; 10..12 measured best
-constexpr uint32_t kDefaultShadowBudget = 10;  // traversal steps of a shadow ray before it is deferred (large scenes); 8..12 measured best at 100 k and 2 M triangles
 void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
-void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
-void launchWfTrace(const RenderArgs& A, uint32_t depth, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s);
+void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 int sceneLdsLevel(const DScene& S);  // 0 = scene in HBM, 1 = object table in LDS, 2 = tree and primitives too
-void launchPairVisible(const RenderArgs& A, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s);
+void launchPairSetup(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
+void launchRaysVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
+void launchPairCompact(const RenderArgs& A, unsigned blocks, hipStream_t s);
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 
 constexpr int kNumCounters = 16;
@@ -60,8 +60,6 @@ void launchEye(const RenderArgs& A, bool stats, hipStream_t s);
 void launchLight(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s);
 void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s);
-void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool stats, hipStream_t s);
-void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,

@@ -50,14 +50,6 @@ DEV bool visible(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty) {
     return visibleBvh(S, p0, p1, st, STATS ? &ty.tc : nullptr);
 }
 
-// visibility with a step budget (trace.h); `first_try` = the ray has not been counted yet
-template <bool STATS>
-DEV int visibleBudget(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty, uint32_t budget, bool first_try) {
-    if (STATS && first_try) ty.shadow++;
-    if (S.accel == 1) return visibleLinear(S, p0, p1, STATS ? &ty.tc : nullptr) ? kVisible : kBlocked;
-    return visibleBvhBudget(S, p0, p1, st, STATS ? &ty.tc : nullptr, budget);
-}
-
 DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_v, uint32_t light_v) {
     atomicAdd(&counters[C_CLOSEST], (unsigned long long)ty.closest);
     atomicAdd(&counters[C_SHADOW], (unsigned long long)ty.shadow);
@@ -492,41 +484,6 @@ DEV uint32_t waveInclusiveScan(uint32_t v) {
     return v;
 }
 
-// One connection of pixel-sample i: everything renderPixel does for one (s,t) (ubdptrenderer.cpp:106-148).
-// The geometric-normal test of connectionFactor (:622-626) runs BEFORE the shadow ray here; it only
-// removes shadow rays whose connection the reference would reject right after tracing them.
-// First half of a connection: the tests that can reject it, ending with the shadow ray.
-template <bool STATS>
-DEV bool pairVisible(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Stack& st, Tally& ty) {
-    const DScene& S = A.S;
-    d3 lpos = A.L.ld3(F_POS, s - 1, i);
-    d3 epos = A.E.ld3(F_POS, t - 1, i);
-    if (t == 1) {
-        uint32_t tx, tyy;
-        if (!t1Pixel(S, lpos, epos, tx, tyy)) return false;
-    }
-    d3 ce = lpos - epos;
-    ce = ce / sqrt(dot(ce, ce));
-    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return false;
-    return visible<STATS>(S, lpos, epos, st, ty);
-}
-// The same with a budget of traversal steps for the shadow ray: kBlocked (or rejected), kVisible, kOutOfBudget.
-template <bool STATS>
-DEV int pairVisibleBudget(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Stack& st, Tally& ty, uint32_t budget,
-                          bool first_try) {
-    const DScene& S = A.S;
-    d3 lpos = A.L.ld3(F_POS, s - 1, i);
-    d3 epos = A.E.ld3(F_POS, t - 1, i);
-    if (t == 1) {
-        uint32_t tx, tyy;
-        if (!t1Pixel(S, lpos, epos, tx, tyy)) return kBlocked;
-    }
-    d3 ce = lpos - epos;
-    ce = ce / sqrt(dot(ce, ce));
-    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) return kBlocked;
-    return visibleBudget<STATS>(S, lpos, epos, st, ty, budget, first_try);
-}
-
 // Second half: connection factor and MIS weight (no ray is traced here). Returns the contribution and the
 // pixel it belongs to; false when the pair contributes nothing.
 template <bool STATS>
@@ -679,109 +636,6 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     }
 }
 
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_pair_process(RenderArgs A) {
-    __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    unsigned long long total = *A.pair_count;
-    if (total > A.pair_capacity) total = A.pair_capacity;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
-    Tally ty;
-    for (unsigned long long j = gid; j < total; j += nthreads) {
-        uint64_t p = A.pairs[j];
-        if (((p >> 8) & 0xff) == 0) continue;
-        connectPair<STATS>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), st, ty);
-    }
-    if (STATS) flushTally(ty, A.counters, 0, 0);
-    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// connections, hybrid form. Lane = pixel-sample (consecutive lanes = consecutive paths, so every
-// vertex field load of the wave is one contiguous run of the [field][slot][path] store). The wave
-// walks the (s,t) grid up to its longest subpaths and looks at each combination with one ballot:
-//   dense  (>= dense_threshold lanes own that pair): evaluated right here, coalesced;
-//   sparse (the long-subpath tail): appended to the pair queue for k_pair_process, where one lane
-//          takes one pair and no lane waits for another's loop.
-// Two sweeps over the grid: the first only counts a lane's sparse pairs so that the wave reserves
-// its queue space with one prefix sum and one atomic.
-// ---------------------------------------------------------------------------------------------------
-DEV uint32_t waveMax(uint32_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        uint32_t o = __shfl_xor(v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_connect_hybrid(RenderArgs A, uint32_t dense_threshold) {
-    __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    bool active = gid < A.E.n;
-    const PathStore& E = A.E;
-    const PathStore& L = A.L;
-    uint32_t nE = 0, nL = 0;
-    // bit k set: vertex k of the subpath may be connected (exists and is not specular); subpaths longer
-    // than 64 vertices keep their first 64 here, the rest is handled by the per-lane loop below
-    unsigned long long okE = 0, okL = 0;
-    if (active) {
-        nE = E.cnt(gid); nL = L.cnt(gid);
-        for (uint32_t t = 0; t < nE && t < 64; t++) okE |= E.specular(t, gid) ? 0ULL : (1ULL << t);
-        for (uint32_t s = 0; s < nL && s < 64; s++) okL |= L.specular(s, gid) ? 0ULL : (1ULL << s);
-    }
-    if (STATS && active) { Tally t0; flushTally(t0, A.counters, nE, nL); }
-    const uint32_t maxE = waveMax(nE < 64 ? nE : 64), maxL = waveMax(nL < 64 ? nL : 64);
-    // sweep 1: count this lane's sparse pairs
-    uint32_t cnt = 0;
-    for (uint32_t s = 1; s <= maxL; s++) {
-        bool hs = (okL >> (s - 1)) & 1;
-        if (__ballot(hs) == 0) continue;
-        for (uint32_t t = 1; t <= maxE; t++) {
-            bool has = hs && ((okE >> (t - 1)) & 1);
-            uint32_t c = (uint32_t)__popcll(__ballot(has));
-            if (has && c < dense_threshold) cnt++;
-        }
-    }
-    uint32_t incl = waveInclusiveScan(cnt);
-    uint32_t total = __shfl(incl, 63, 64);
-    unsigned long long base = 0;
-    if ((threadIdx.x & 63) == 0 && total) base = atomicAdd(A.pair_count, (unsigned long long)total);
-    base = __shfl(base, 0, 64);
-    unsigned long long pos = base + (incl - cnt);
-    const bool queue_ok = pos + cnt <= A.pair_capacity;
-    if (!queue_ok)  // queue full: skip records in the reserved part, the pairs are evaluated below
-        for (unsigned long long j = pos; j < pos + cnt && j < A.pair_capacity; j++) A.pairs[j] = 0;
-    // sweep 2: evaluate dense combinations, queue sparse ones
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
-    Tally ty;
-    for (uint32_t s = 1; s <= maxL; s++) {
-        bool hs = (okL >> (s - 1)) & 1;
-        if (__ballot(hs) == 0) continue;
-        for (uint32_t t = 1; t <= maxE; t++) {
-            bool has = hs && ((okE >> (t - 1)) & 1);
-            uint32_t c = (uint32_t)__popcll(__ballot(has));
-            if (!has) continue;
-            if (c >= dense_threshold || !queue_ok) connectPair<STATS>(A, gid, s, t, st, ty);
-            else A.pairs[pos++] = packPair(gid, s, t);
-        }
-    }
-    // subpaths beyond 64 vertices (only possible with max_path_vertices > 64): plain per-lane loop
-    if (active && (nE > 64 || nL > 64)) {
-        for (uint32_t s = 1; s <= nL; s++) {
-            if (L.specular(s - 1, gid)) continue;
-            for (uint32_t t = 1; t <= nE; t++) {
-                if ((s <= 64 && t <= 64) || E.specular(t - 1, gid)) continue;
-                connectPair<STATS>(A, gid, s, t, st, ty);
-            }
-        }
-    }
-    if (STATS) flushTally(ty, A.counters, 0, 0);
-    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
-}
-
 }  // namespace ub
 #include "wavefront_split.h"
 namespace ub {
@@ -931,10 +785,6 @@ void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_wf_gen<true>, dim3(g), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_wf_gen<false>, dim3(g), dim3(kBlock), 0, s, A);
 }
-void launchWfBounce(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_wf_bounce<true>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
-    else hipLaunchKernelGGL(k_wf_bounce<false>, dim3(blocks), dim3(kBlock), 0, s, A, depth);
-}
 // picks the instantiation (counting or not, how much of the scene fits into LDS) of a kernel template K<bool, int>
 #define UBDPT_LAUNCH_TRACE(K, ...)                                                                             \
     do {                                                                                                       \
@@ -956,10 +806,6 @@ void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_enum<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
 }
-void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_connect_hybrid<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A, dense_threshold);
-    else hipLaunchKernelGGL(k_connect_hybrid<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A, dense_threshold);
-}
 // picks the instantiation (counting or not, object table in LDS or not) of a kernel template K<bool, uint32_t>
 #define UBDPT_LAUNCH_LDS(K, CAP, ...)                                                                          \
     do {                                                                                                       \
@@ -972,24 +818,26 @@ void launchConnectHybrid(const RenderArgs& A, uint32_t dense_threshold, bool sta
             else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
         }                                                                                                      \
     } while (0)
-void launchWfTrace(const RenderArgs& A, uint32_t depth, uint32_t round, uint32_t budget, unsigned blocks, bool stats,
-                   hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth, round, budget);
+void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
+    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
     UBDPT_LAUNCH_LDS(k_wf_shade, kLdsObjectsShade, A, depth);
 }
 int sceneLdsLevel(const DScene& S) { return ldsLevelFor(S); }
-void launchPairVisible(const RenderArgs& A, uint32_t round, uint32_t budget, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_pair_visible, A, round, budget);
+void launchPairSetup(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_pair_setup<true>, dim3(blocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_setup<false>, dim3(blocks), dim3(kBlock), 0, s, A);
+}
+void launchRaysVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
+    UBDPT_LAUNCH_TRACE(k_rays_visible, A);
+}
+void launchPairCompact(const RenderArgs& A, unsigned blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_pair_compact, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_eval<false>, dim3(blocks), dim3(kBlock), 0, s, A);
-}
-void launchPairProcess(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
-    if (stats) hipLaunchKernelGGL(k_pair_process<true>, dim3(blocks), dim3(kBlock), 0, s, A);
-    else hipLaunchKernelGGL(k_pair_process<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {

@@ -342,11 +342,8 @@ DEV Closest closestHitLinear(const DScene& S, const Ray& r, TraceCounters* tc) {
     return best;
 }
 
-DEV bool visibleLinear(const DScene& S, d3 p0, d3 p1, TraceCounters* tc) {
-    double dist = length(p1 - p0);
-    Ray r;
-    r.o = p0;
-    r.d = (p1 - p0) / dist;
+// `r` = the ray UScene::visibility builds from its two points (uscene.cpp:24-27), dist = their distance
+DEV bool visibleLinearRay(const DScene& S, const Ray& r, double dist, TraceCounters* tc) {
     for (uint32_t o = 0; o < S.num_objects; o++) {
         const DObject& ob = S.objects[o];
         Ray l = toLocal(ob.invW, r);
@@ -370,6 +367,13 @@ DEV bool visibleLinear(const DScene& S, d3 p0, d3 p1, TraceCounters* tc) {
         }
     }
     return true;
+}
+DEV bool visibleLinear(const DScene& S, d3 p0, d3 p1, TraceCounters* tc) {
+    double dist = length(p1 - p0);
+    Ray r;
+    r.o = p0;
+    r.d = (p1 - p0) / dist;
+    return visibleLinearRay(S, r, dist, tc);
 }
 
 // ---- surface point of the winning candidate, object-local space ------------------------------------

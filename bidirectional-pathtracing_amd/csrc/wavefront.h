@@ -5,14 +5,11 @@
 // ends. Here every bounce is one launch over the compacted queue of live subpaths:
 //
 //   k_wf_gen     primary rays (camera, :231-257) and emission rays (:413-454) for the whole batch
-//   k_wf_bounce  per workgroup chunk of 256 live subpaths:
-//                (1) closest hit through the LBVH and lobe choice (uapp/material.h);
-//                (2) counting sort of the chunk by (eye|light, lobe) in LDS: the lobe queues live
-//                    in LDS, and after the sort a wave shades one BSDF;
-//                (3) Russian roulette and pdf bookkeeping for the hit, s=0 emission sample, BSDF
-//                    sampling, vertex push, next ray;
-//                (4) survivors are appended to the next queue: ballot per wave, ONE global atomic
-//                    per chunk.
+//   k_wf_trace   closest hit of every live subpath's ray (wavefront_split.h)
+//   k_wf_shade   per workgroup chunk of 256 traced subpaths: lobe choice (uapp/material.h), counting sort of
+//                the chunk by (eye|light, lobe) in LDS, then Russian roulette and pdf bookkeeping for the hit,
+//                s=0 emission sample, BSDF sampling, vertex push, next ray; survivors are appended to the
+//                next queue with ONE global atomic per chunk (wavefront_split.h)
 //   k_wf_tail    after the wavefront bounces the few survivors (long specular chains) finish in a per-lane loop
 //
 // Subpath id: [0, N) are the eye subpaths, [N, 2N) the light subpaths of the batch's N pixel-samples.
@@ -296,119 +293,6 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             else storeCarryRay(A, id, cy);  // the rest of an eye subpath's first record is constant, see loadCarry
         }
     }
-}
-
-// ---- one bounce of every live subpath -------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_wf_bounce(RenderArgs A, uint32_t depth) {
-    __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    __shared__ uint32_t s_id[kBlock];
-    __shared__ int32_t s_obj[kBlock];
-    __shared__ uint32_t s_face[kBlock];
-    __shared__ double s_d[kBlock], s_u[kBlock], s_v[kBlock];
-    __shared__ uint32_t s_cnt[kWfRegions + 1];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_base;
-    const DScene& S = A.S;
-    const uint64_t N = A.E.n;
-    const uint32_t tid = threadIdx.x;
-    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
-    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    // depth 0 walks all 2N subpaths in id order, later depths the queue the previous bounce wrote
-    const uint64_t total = depth == 0 ? 2 * N : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
-    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * 2 * N;
-    uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
-    uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * 2 * N;
-    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
-    Tally ty;
-    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
-        if (tid <= kWfRegions) s_cnt[tid] = 0;
-        __syncthreads();
-        // (1) trace + lobe choice
-        uint64_t j = base + tid;
-        int region = kWfRegions;  // dead
-        uint32_t id = 0;
-        Closest hit;
-        hit.object = -1; hit.face = 0; hit.d = 0; hit.u = 0; hit.v = 0;
-        if (j < total) {
-            id = depth == 0 ? (uint32_t)j : q[j];
-            bool light = id >= N;
-            uint64_t i = light ? id - N : id;
-            const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.cnt(i);
-            if (n > 0) {
-                Ray ray;
-                loadCarryRay(A, id, ray);
-                hit = closestHit<STATS>(S, ray, st, ty);
-                if (hit.object >= 0) {
-                    uint64_t pixel;
-                    Rng rng = pathRng(A, i, light, pixel);
-                    int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
-                    // a light subpath ends at an absorbing hit (:460, :527)
-                    if (!(light && lobe == LOBE_NONE)) region = (light ? 4 : 0) + lobe + 1;
-                }
-            }
-        }
-        // (2) counting sort of the chunk by region, in LDS
-        uint32_t rank = 0;
-        if (region < kWfRegions) rank = atomicAdd(&s_cnt[region], 1u);
-        __syncthreads();
-        uint32_t start[kWfRegions + 1];
-        start[0] = 0;
-#pragma unroll
-        for (int r = 0; r < kWfRegions; r++) start[r + 1] = start[r] + s_cnt[r];
-        const uint32_t live = start[kWfRegions];
-        if (region < kWfRegions) {
-            uint32_t slot = rank;
-#pragma unroll
-            for (int r = 0; r < kWfRegions; r++) slot += (r < region) ? s_cnt[r] : 0u;
-            s_id[slot] = id; s_obj[slot] = hit.object; s_face[slot] = hit.face;
-            s_d[slot] = hit.d; s_u[slot] = hit.u; s_v[slot] = hit.v;
-        }
-        __syncthreads();
-        // (3) shade the sorted chunk: lanes [start[r], start[r+1]) run lobe queue r
-        bool cont = false;
-        uint32_t sid = 0;
-        if (tid < live) {
-            int r = 0;
-#pragma unroll
-            for (int k = 1; k < kWfRegions; k++) r += (tid >= start[k]) ? 1 : 0;
-            sid = s_id[tid];
-            Closest h2;
-            h2.object = s_obj[tid]; h2.face = s_face[tid]; h2.d = s_d[tid]; h2.u = s_u[tid]; h2.v = s_v[tid];
-            bool light = r >= 4;
-            int lobe = (r & 3) - 1;
-            uint64_t i = light ? sid - N : sid;
-            const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.cnt(i);
-            uint64_t pixel;
-            Rng rng = pathRng(A, i, light, pixel);
-            Carry cy;
-            loadCarry(A, sid, cy, !light && n == 1);
-            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, h2, lobe, cy, ty)
-                         : shadeStep<STATS, false>(A, i, pixel, rng, n, h2, lobe, cy, ty);
-            if (cont) storeCarry(A, sid, cy);
-        }
-        // (4) survivors -> next queue, one global atomic per chunk
-        unsigned long long m = __ballot(cont);
-        if ((tid & 63) == 0) s_wave[tid >> 6] = (uint32_t)__popcll(m);
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) tot += s_wave[w];
-            s_base = tot ? atomicAdd(&next_cnt[0], tot) : 0u;
-        }
-        __syncthreads();
-        if (cont) {
-            uint32_t pos = s_base + (uint32_t)__popcll(m & ((1ULL << (tid & 63)) - 1ULL));
-            for (uint32_t w = 0; w < (tid >> 6); w++) pos += s_wave[w];
-            next_q[pos] = sid;
-        }
-        __syncthreads();
-    }
-    if (STATS) flushTally(ty, A.counters, 0, 0);
-    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
 // ---- tail: survivors of the last wavefront bounce finish in a per-lane loop ---------------------------

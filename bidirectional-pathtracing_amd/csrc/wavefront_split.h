@@ -4,29 +4,29 @@
 // memory phases, and a kernel that holds the traversal state AND the fp64 shading state needs
 // >200 VGPRs (2 waves per SIMD). Splitting at the natural seams keeps each kernel's live state small:
 //
-//   k_wf_trace     ray in, (object, face, d, u, v, lobe) out; the 256 subpaths of a chunk are ordered by
-//                  (eye|light, lobe) with a stable counting sort in LDS and appended to the hit
-//                  queue as one block: one global atomic per chunk, chunks padded to whole waves so
-//                  that a wave of the shade kernel sees one lobe (material-sorted queue)
-//   k_wf_shade     no traversal: pdf bookkeeping, s=0 sample, BSDF sampling, vertex push, next ray;
-//                  survivors -> next trace queue (one atomic per chunk)
-//   k_pair_visible the rejecting half of a connection, ending with the shadow ray; survivors -> queue
+//   k_wf_trace     ray in, (object, face, d, u, v) out. Persistent waves: a wave claims chunks of the trace queue and
+//                  every lane that has finished its ray takes the next one while the other lanes go on walking
+//   k_wf_shade     per workgroup chunk of 256 traced subpaths: lobe choice, stable counting sort of the chunk by
+//                  (eye|light, lobe) in LDS so that a wave sees one BSDF (material-sorted queue), then pdf
+//                  bookkeeping, s=0 sample, BSDF sampling, vertex push, next ray; survivors -> next trace queue
+//   k_pair_setup   the rejecting tests of a connection that need no ray (t=1 projection, geometric-normal
+//                  cosines); the shadow rays of the pairs that pass, as 64-byte records in a dense queue
+//   k_rays_visible the shadow rays, persistent waves like k_wf_trace; one flag per ray
+//   k_pair_compact pairs with a visible ray -> queue
 //   k_pair_eval    connection factor, MIS weight, accumulation for the visible pairs only
 #pragma once
 
 namespace ub {
 
-constexpr uint32_t kQueueSentinel = 0xffffffffu;
-
 // Waves per SIMD the ray-tracing kernels are compiled for (register budget = 512 / this; 1 = whatever the
-// compiler needs, which comes to 4). A scene that lives in LDS leaves room for 4 workgroups per CU and its rays
-// are bound by arithmetic. Rays that walk a tree in HBM wait on dependent node fetches: for them a fifth wave per
-// SIMD is worth the handful of spilled registers it costs (+7 % on scenes of 100 k and 2 M triangles).
+// compiler needs, which comes to 4). Measured on the 2 M-triangle scene with the persistent-wave kernels below:
+// 4 waves (128 registers, nothing spilled) 218 Mpaths/s, 5 waves (96 registers, 12..32 spilled inside the loop) 178,
+// 3 waves 210.
 #ifndef UBDPT_TRACE_WAVES
 #define UBDPT_TRACE_WAVES 1
 #endif
 #ifndef UBDPT_TRACE_WAVES_HBM
-#define UBDPT_TRACE_WAVES_HBM 5
+#define UBDPT_TRACE_WAVES_HBM 4
 #endif
 constexpr int traceWaves(int lds_level) { return lds_level >= 2 ? UBDPT_TRACE_WAVES : UBDPT_TRACE_WAVES_HBM; }
 // the same for the shading and the connection evaluation kernel
@@ -61,20 +61,76 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
     return pos;
 }
 
-// ---- trace ------------------------------------------------------------------------------------------------
-// round 0 reads the trace queue of this depth and gives every ray `budget` traversal steps; a ray that runs out of
-// them leaves its closest candidate so far in its hit record and its id in the deferred queue, which round 1
-// (budget 0xffffffff) finishes: the long rays together instead of one per wave holding 63 idle lanes.
-// budget 0xffffffff in round 0: no ray is deferred and there is no round 1.
+// ---- persistent-wave ray tracing -----------------------------------------------------------------------------
+// The steps a ray needs to cross the tree are heavy-tailed: on a 2 M-triangle scene the mean shadow ray visits 9
+// nodes, but the slowest of 64 rays visits 80, so a wave that traces 64 rays side by side keeps 7 of its 64
+// lanes busy. Here a wave is a pool of 64 lanes fed from a queue: the wave claims chunks of kRayChunk queue
+// entries (one atomic per chunk), and whenever kRefillMin lanes have finished their rays they take the next
+// entries while the other lanes go on walking. A new ray's record is REQUESTED in one iteration and used in the
+// next, so its load completes under the wait for the tree nodes the walking lanes fetch anyway: refilling never
+// stalls the wave. Leaves are tested when kLeafBatch lanes hold one (or nothing else can make progress, or a
+// lane has waited kLeafWait node steps), so the fp64 primitive test runs for many lanes at once.
+#ifndef UBDPT_RAY_CHUNK
+#define UBDPT_RAY_CHUNK 256
+#endif
+#ifndef UBDPT_REFILL_MIN
+#define UBDPT_REFILL_MIN 16
+#endif
+#ifndef UBDPT_LEAF_BATCH
+#define UBDPT_LEAF_BATCH 12
+#endif
+#ifndef UBDPT_LEAF_WAIT
+#define UBDPT_LEAF_WAIT 3
+#endif
+constexpr uint32_t kRayChunk = UBDPT_RAY_CHUNK;
+constexpr int kRefillMin = UBDPT_REFILL_MIN;
+constexpr int kLeafBatch = UBDPT_LEAF_BATCH;
+constexpr uint32_t kLeafWait = UBDPT_LEAF_WAIT;
+enum { ST_IDLE = 0, ST_ID = 1, ST_RAY = 2, ST_ACTIVE = 3 };
+
+// Wave-uniform view of the queue a persistent wave feeds from.
+struct WaveFeed {
+    uint32_t next, end;  // unread part of the chunk this wave holds
+    bool drained;        // the queue has nothing left for this wave
+};
+// Entries a wave claims at a time: kRayChunk when the queue is long, fewer (at least 64) when that would leave
+// waves of the launch without work.
+DEV uint32_t chunkFor(uint32_t total) {
+    const uint32_t waves = gridDim.x * (kBlock / 64);
+    uint32_t c = (total / waves) & ~63u;
+    return c < 64u ? 64u : (c > kRayChunk ? kRayChunk : c);
+}
+// Hands the idle lanes (mask idle_m) their next queue positions. Every lane of the wave must call it.
+// Returns true for a lane that got one (in idx).
+DEV bool feedLanes(WaveFeed& f, uint32_t* head, uint32_t total, uint32_t chunk, unsigned long long idle_m, bool idle,
+                   uint32_t& idx) {
+    const uint32_t lane = threadIdx.x & 63;
+    if (f.next == f.end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(head, chunk);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= total) { f.drained = true; return false; }
+        f.next = base;
+        f.end = base + chunk < total ? base + chunk : total;
+    }
+    const uint32_t nidle = (uint32_t)__popcll(idle_m);
+    const uint32_t avail = f.end - f.next;
+    const uint32_t take = nidle < avail ? nidle : avail;
+    const uint32_t rank = (uint32_t)__popcll(idle_m & ((1ULL << lane) - 1ULL));
+    const bool got = idle && rank < take;
+    if (got) idx = f.next + rank;
+    f.next += take;
+    return got;
+}
+
+// ---- trace: closest hits of the subpath rays of one depth ------------------------------------------------------
+// Queue entry j of depth `depth` is subpath id q[j] (depth 0: id = j); its ray is the first line of its carry
+// record. The closest hit (object -1: none) goes to the subpath's hit record.
 // (Generating the subpaths inside the first launch of this kernel instead of in k_wf_gen was measured: the generation
 // code costs the kernel a quarter of its occupancy, inlined or not, and the whole is slower: 411 against 418 Mpaths/s.)
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth, uint32_t round,
-                                                                         uint32_t budget) {
+__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_base;
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
     __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
     __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
@@ -84,58 +140,156 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
     const DScene& S = A.S;
     const uint64_t N = A.E.n;
     const uint64_t n2 = 2 * N;
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
-    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
-    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    const bool first = round == 0;
-    uint32_t* defer_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 2;
-    const uint64_t total = !first ? (uint64_t)*defer_cnt : depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
-    const uint32_t* q = first ? A.wf_trace_q + (uint64_t)(depth & 1) * n2 : A.wf_defer_q;
-    uint32_t* hit_cnt = A.wf_count + (uint64_t)depth * kWfQStride + 1;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t total = depth == 0 ? (uint32_t)n2 : A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * n2;
+    uint32_t* head = A.wf_count + (uint64_t)depth * kWfQStride + 3;
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
-    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
-        uint64_t j = base + tid;
-        int region = kWfRegions;  // dead
-        uint32_t id = 0;
-        bool deferred = false;
-        if (j < total) {
-            id = (first && depth == 0) ? (uint32_t)j : q[j];
-            bool light = id >= N;
-            uint64_t i = light ? id - N : id;
-            const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.cnt(i);
-            if (n > 0) {
-                Ray ray;
-                loadCarryRay(A, id, ray);
-                Closest hit;
-                if (first) {
-                    hit.d = __builtin_inf(); hit.u = 0; hit.v = 0; hit.object = -1; hit.face = 0;
-                    if (STATS) ty.closest++;
+    TraceCounters* tc = STATS ? &ty.tc : nullptr;
+    WaveFeed feed;
+    feed.next = feed.end = 0; feed.drained = total == 0;
+    const uint32_t chunk = chunkFor(total);
+    int state = ST_IDLE;
+    uint32_t idx = 0, id = 0, leaf_wait = 0;
+    Ray ray;
+    ray.o = ray.d = mk3(0, 0, 0);
+    uint32_t cnt_word = 0;
+    RayF rq = makeRayF(ray);
+    float tmax = 0;
+    int32_t node = kTraversalDone;
+    Closest best;
+    best.d = 0; best.u = 0; best.v = 0; best.object = -1; best.face = 0;
+    LocalCache c;
+    c.object = -1; c.gate_object = -1; c.gate_ok = false;
+    for (;;) {
+        // (1) lanes whose request of the previous iteration has arrived
+        if (state == ST_RAY) {
+            best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
+            if ((cnt_word & 0xffu) == 0) {  // no subpath under this id (light subpaths of a scene without emitters)
+                state = ST_IDLE;
+            } else if (S.num_prims == 0) {
+                if (STATS) ty.closest++;
+                storeHit(A, id, best);
+                state = ST_IDLE;
+            } else if (S.accel == 1) {
+                if (STATS) ty.closest++;
+                best = closestHitLinear(S, ray, tc);
+                storeHit(A, id, best);
+                state = ST_IDLE;
+            } else {
+                if (STATS) ty.closest++;
+                rq = makeRayF(ray);
+                tmax = floatUp(best.d);
+                c.object = -1; c.gate_object = -1; c.gate_ok = false;
+                st.sp = 0;
+                node = 0;
+                state = ST_ACTIVE;
+            }
+        }
+        if (state == ST_ID) {
+            const double* p = A.carry + (uint64_t)id * kCarryDoubles;
+            ray.o = mk3(p[0], p[1], p[2]);
+            ray.d = mk3(p[3], p[4], p[5]);
+            cnt_word = reinterpret_cast<const uint32_t*>(p + kCarryCountSlot)[0];
+            state = ST_RAY;
+        }
+        // (2) idle lanes take the next queue entries
+        const unsigned long long idle_m = __ballot(state == ST_IDLE);
+        const unsigned long long act_m = __ballot(state == ST_ACTIVE);
+        if (!feed.drained && ((int)__popcll(idle_m) >= kRefillMin || act_m == 0)) {
+            if (feedLanes(feed, head, total, chunk, idle_m, state == ST_IDLE, idx)) {
+                if (depth == 0) {  // uniform
+                    id = idx;
+                    const double* p = A.carry + (uint64_t)id * kCarryDoubles;
+                    ray.o = mk3(p[0], p[1], p[2]);
+                    ray.d = mk3(p[3], p[4], p[5]);
+                    cnt_word = reinterpret_cast<const uint32_t*>(p + kCarryCountSlot)[0];
+                    state = ST_RAY;
                 } else {
-                    loadHit(A, id, hit);  // the closest candidate round 0 had found when its budget ran out
-                }
-                if (S.accel == 1) hit = closestHitLinear(S, ray, STATS ? &ty.tc : nullptr);
-                else deferred = !closestHitBvhBudget(S, ray, st, STATS ? &ty.tc : nullptr, budget, hit);
-                if (deferred) {
-                    storeHit(A, id, hit);
-                } else if (hit.object >= 0) {
-                    uint64_t pixel;
-                    Rng rng = pathRng(A, i, light, pixel);
-                    int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
-                    if (!(light && lobe == LOBE_NONE)) {  // a light subpath ends at an absorbing hit (:460, :527)
-                        region = (light ? 4 : 0) + lobe + 1;
-                        storeHit(A, id, hit);
-                    }
+                    id = q[idx];
+                    state = ST_ID;
                 }
             }
         }
-        if (budget != 0xffffffffu) {  // uniform
-            uint32_t dpos = blockAppend(deferred, defer_cnt, s_wave, &s_base);
-            if (deferred) A.wf_defer_q[dpos] = id;
+        if (feed.drained && idle_m == ~0ULL) break;
+        if (act_m == 0) continue;
+        // (3) one node step for every lane that stands at an inner node
+        if (state == ST_ACTIVE && node >= 0) {
+            node = descend(S, node, rq, tmax, st, true, tc);
+            if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
         }
-        // stable counting sort of the chunk by region: rank inside the wave by ballot, wave totals in LDS
+        // (4) primitive tests, once enough lanes hold a leaf or nothing else can move
+        const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
+        if (leaf_m != 0) {
+            const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
+                leaf_wait = 0;
+                if (state == ST_ACTIVE && node < 0) {
+                    if (STATS) { tc->prims++; countWaveStep(tc->wave_prims); }
+                    testPrimClosest(S, ray, S.prims[~node], c, best);
+                    tmax = floatUp(best.d);
+                    node = st.sp ? st.pop() : kTraversalDone;
+                    if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
+                }
+            }
+        }
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---- shade ------------------------------------------------------------------------------------------------
+// A workgroup takes 256 consecutive entries of the depth's trace queue: every lane looks at its subpath's hit
+// record and draws the lobe (uapp/material.h), the chunk is ordered by (eye|light, lobe) with a stable counting
+// sort in LDS (rank inside the wave by ballot, wave totals in LDS), and lane k then shades the k-th entry of the
+// sorted chunk: the lanes of a wave run one BSDF. Misses and light subpaths that end at an absorbing hit
+// (ubdptrenderer.cpp:460, :527) drop out in the sort.
+// (Keeping the corner positions and shading attributes of the faces of a small scene in LDS as well removes the
+// last dependent global fetch between a hit and its stores; measured: no difference, the kernel is bound by its
+// stores.)
+template <bool STATS, uint32_t LDS_OBJECTS>
+__global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderArgs A0, uint32_t depth) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_wcnt[kWfRegions][kBlock / 64];
+    __shared__ uint32_t s_sorted[kBlock];
+    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
+    RenderArgs A = A0;
+    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
+    const DScene& S = A.S;
+    const uint64_t N = A.E.n;
+    const uint64_t n2 = 2 * N;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint64_t total = depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * n2;
+    uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
+    uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * n2;
+    Tally ty;
+    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
+        const uint64_t j = base + tid;
+        int region = kWfRegions;  // dead
+        uint32_t id = 0;
+        if (j < total) {
+            id = depth == 0 ? (uint32_t)j : q[j];
+            const bool light = id >= N;
+            const uint64_t i = light ? id - N : id;
+            const PathStore& P = light ? A.L : A.E;
+            const uint32_t n = P.cnt(i);
+            if (n > 0) {
+                const unsigned long long w = (unsigned long long)__double_as_longlong(A.wf_hit[(uint64_t)id * kHitDoubles + 3]);
+                const int32_t object = (int32_t)(uint32_t)w;
+                if (object >= 0) {
+                    uint64_t pixel;
+                    Rng rng = pathRng(A, i, light, pixel);
+                    const int lobe = pickLobe(S.objects[object], rng(hitDim(n, DIM_LOBE)));
+                    if (!(light && lobe == LOBE_NONE)) region = (light ? 4 : 0) + lobe + 1;
+                }
+            }
+        }
+        // stable counting sort of the chunk by region
         uint32_t rank = 0;
 #pragma unroll
         for (int r = 0; r < kWfRegions; r++) {
@@ -149,119 +303,196 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
         for (int r = 0; r < kWfRegions; r++)
 #pragma unroll
             for (int w = 0; w < kBlock / 64; w++) {
-                uint32_t c = s_wcnt[r][w];
-                live += c;
-                if (r < region || (r == region && (uint32_t)w < wave)) slot += c;
+                uint32_t cw = s_wcnt[r][w];
+                live += cw;
+                if (r < region || (r == region && (uint32_t)w < wave)) slot += cw;
             }
-        const uint32_t padded = (live + 63u) & ~63u;  // whole waves: a shade wave never straddles two chunks
-        if (tid == 0) s_base = padded ? atomicAdd(hit_cnt, padded) : 0u;
+        if (region < kWfRegions) s_sorted[slot] = id | ((uint32_t)region << 29);
         __syncthreads();
-        if (region < kWfRegions) A.wf_hit_q[s_base + slot] = id | ((uint32_t)region << 29);
-        if (tid < padded - live) A.wf_hit_q[s_base + live + tid] = kQueueSentinel;
-        __syncthreads();
+        bool cont = false;
+        uint32_t sid = 0;
+        if (tid < live) {
+            const uint32_t e = s_sorted[tid];
+            sid = e & 0x1fffffffu;
+            const uint32_t r = e >> 29;
+            const bool light = r >= 4;
+            const int lobe = (int)(r & 3) - 1;
+            const uint64_t i = light ? sid - N : sid;
+            const PathStore& P = light ? A.L : A.E;
+            uint32_t n = P.cnt(i);
+            uint64_t pixel;
+            Rng rng = pathRng(A, i, light, pixel);
+            Carry cy;
+            loadCarry(A, sid, cy, !light && n == 1);
+            Closest hit;
+            loadHit(A, sid, hit);
+            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
+                         : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
+            if (cont) storeCarry(A, sid, cy);
+        }
+        uint32_t pos = blockAppend(cont, &next_cnt[0], s_wave, &s_base);  // ends with a barrier: s_sorted / s_wcnt are free again
+        if (cont) next_q[pos] = sid;
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
-    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
-// ---- shade ------------------------------------------------------------------------------------------------
-// (Keeping the corner positions and shading attributes of the faces of a small scene in LDS as well removes the
-// last dependent global fetch between a hit and its stores; measured: no difference, the kernel is bound by its
-// stores.)
-template <bool STATS, uint32_t LDS_OBJECTS>
-__global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderArgs A0, uint32_t depth) {
+// ---- connections: the shadow rays of the pairs, visibility, then evaluation ---------------------------------
+// One connection of pixel-sample i: everything renderPixel does for one (s,t) before it traces the shadow ray
+// (ubdptrenderer.cpp:106-131) plus the geometric-normal test of connectionFactor (:622-626), which runs BEFORE the
+// shadow ray here: it only removes shadow rays whose connection the reference would reject right after tracing them.
+// The ray is the one UScene::visibility builds (uscene.cpp:21-27): from the light vertex towards the eye vertex.
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_setup(RenderArgs A) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
-    __shared__ DObject s_objects[LDS_OBJECTS ? LDS_OBJECTS : 1];
-    RenderArgs A = A0;
-    if (LDS_OBJECTS) A.S.objects = stageObjects(A0.S, s_objects);
-    const uint64_t N = A.E.n;
-    const uint64_t n2 = 2 * N;
+    const DScene& S = A.S;
     const uint32_t tid = threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    const uint64_t total = (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride + 1];
-    uint32_t* next_cnt = A.wf_count + (uint64_t)(depth + 1) * kWfQStride;
-    uint32_t* next_q = A.wf_trace_q + (uint64_t)((depth + 1) & 1) * n2;
+    unsigned long long total = *A.pair_count;
+    if (total > A.pair_capacity) total = A.pair_capacity;
     Tally ty;
-    for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < total; base += nthreads) {
-        uint64_t j = base + tid;
-        bool cont = false;
-        uint32_t id = 0;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
+        const unsigned long long j = base + tid;
+        bool ok = false;
+        uint64_t p = 0;
+        d3 lpos = mk3(0, 0, 0), epos = mk3(0, 0, 0);
         if (j < total) {
-            uint32_t e = A.wf_hit_q[j];
-            if (e != kQueueSentinel) {
-                id = e & 0x1fffffffu;
-                uint32_t r = e >> 29;
-                bool light = r >= 4;
-                int lobe = (int)(r & 3) - 1;
-                uint64_t i = light ? id - N : id;
-                const PathStore& P = light ? A.L : A.E;
-                uint32_t n = P.cnt(i);
-                uint64_t pixel;
-                Rng rng = pathRng(A, i, light, pixel);
-                Carry cy;
-                loadCarry(A, id, cy, !light && n == 1);
-                Closest hit;
-                loadHit(A, id, hit);
-                cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
-                             : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
-                if (cont) storeCarry(A, id, cy);
+            p = A.pairs[j];
+            const uint32_t s = (uint32_t)((p >> 8) & 0xff), t = (uint32_t)(p & 0xff);
+            const uint64_t i = p >> 16;
+            if (s != 0) {
+                lpos = A.L.ld3(F_POS, s - 1, i);
+                epos = A.E.ld3(F_POS, t - 1, i);
+                ok = true;
+                if (t == 1) {
+                    uint32_t tx, tyy;
+                    ok = t1Pixel(S, lpos, epos, tx, tyy);
+                }
+                if (ok) {
+                    d3 ce = lpos - epos;
+                    ce = ce / sqrt(dot(ce, ce));
+                    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) ok = false;
+                }
             }
         }
-        uint32_t pos = blockAppend(cont, &next_cnt[0], s_wave, &s_base);
-        if (cont) next_q[pos] = id;
+        const uint32_t pos = blockAppend(ok, A.ray_count, s_wave, &s_base);
+        if (ok) {  // rays never outnumber pairs, and the ray queue holds as many entries as the pair queue
+            const double dist = length(epos - lpos);
+            const d3 dir = (epos - lpos) / dist;
+            double* o = A.rays + (uint64_t)pos * kRayDoubles;
+            o[0] = lpos.x; o[1] = lpos.y; o[2] = lpos.z;
+            o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
+            o[6] = dist;
+            o[7] = __longlong_as_double((long long)p);
+        }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
 }
 
-// ---- connections: visibility, then evaluation -----------------------------------------------------------
-// round 0 reads the pair queue, round r > 0 the deferred queue (r - 1) & 1. Every shadow ray gets a budget of
-// `budget` traversal steps; the pairs whose ray runs out of it go to the deferred queue r & 1 for the next round
-// (budget 0xffffffff: no ray is ever deferred; the last round must be launched with it).
+// UScene::visibility (uscene.cpp:28-38) for every ray of the queue: flag 1 when nothing blocks it.
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_pair_visible(RenderArgs A0, uint32_t round, uint32_t budget) {
+__global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(RenderArgs A0) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_base;
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
     __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
     __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
     if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
     if (LDS_LEVEL >= 2) stageTree(A.S, s_nodes, s_prims);
-    const uint32_t tid = threadIdx.x;
-    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
-    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
-    const bool first = round == 0;
-    // (no dynamic index into the local copy A: it would be moved to scratch memory as a whole)
-    const bool odd = round & 1;
-    uint64_t* defer_q = odd ? A0.defer_pairs[1] : A0.defer_pairs[0];
-    uint32_t* defer_n = odd ? A0.defer_count[1] : A0.defer_count[0];
-    const uint64_t* prev_q = odd ? A0.defer_pairs[0] : A0.defer_pairs[1];
-    const uint32_t* prev_n = odd ? A0.defer_count[0] : A0.defer_count[1];
-    unsigned long long total = first ? *A.pair_count : (unsigned long long)*prev_n;
-    if (total > A.pair_capacity) total = A.pair_capacity;
-    const uint64_t* queue = first ? A.pairs : prev_q;
+    const DScene& S = A.S;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    unsigned long long total64 = *A.ray_count;
+    if (total64 > A.pair_capacity) total64 = A.pair_capacity;
+    const uint32_t total = (uint32_t)total64;
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
     Tally ty;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
-        unsigned long long j = base + tid;
-        int r = kBlocked;
-        uint64_t p = 0;
-        if (j < total) {
-            p = queue[j];
-            uint32_t s = (uint32_t)((p >> 8) & 0xff), t = (uint32_t)(p & 0xff);
-            if (s != 0) r = pairVisibleBudget<STATS>(A, p >> 16, s, t, st, ty, budget, first);
+    TraceCounters* tc = STATS ? &ty.tc : nullptr;
+    WaveFeed feed;
+    feed.next = feed.end = 0; feed.drained = total == 0;
+    const uint32_t chunk = chunkFor(total);
+    int state = ST_IDLE;
+    uint32_t idx = 0, leaf_wait = 0;
+    Ray ray;
+    ray.o = ray.d = mk3(0, 0, 0);
+    double dist = 0;
+    RayF rq = makeRayF(ray);
+    float tmax = 0;
+    int32_t node = kTraversalDone;
+    LocalCache c;
+    c.object = -1; c.gate_object = -1; c.gate_ok = false;
+    for (;;) {
+        // (1) rays requested in the previous iteration
+        if (state == ST_RAY) {
+            if (STATS) ty.shadow++;
+            if (S.num_prims == 0) {
+                A.ray_flag[idx] = 1;
+                state = ST_IDLE;
+            } else if (S.accel == 1) {
+                A.ray_flag[idx] = visibleLinearRay(S, ray, dist, tc) ? 1 : 0;
+                state = ST_IDLE;
+            } else {
+                rq = makeRayF(ray);
+                tmax = floatUp(dist);
+                c.object = -1; c.gate_object = -1; c.gate_ok = false;
+                st.sp = 0;
+                node = 0;
+                state = ST_ACTIVE;
+            }
         }
-        uint32_t pos = blockAppend(r == kVisible, A.vis_count, s_wave, &s_base);
-        if (r == kVisible) A.vis_pairs[pos] = p;
-        if (budget != 0xffffffffu) {  // uniform; a deferred queue holds as many entries as the pair queue
-            pos = blockAppend(r == kOutOfBudget, defer_n, s_wave, &s_base);
-            if (r == kOutOfBudget) defer_q[pos] = p;
+        // (2) idle lanes take the next rays
+        const unsigned long long idle_m = __ballot(state == ST_IDLE);
+        const unsigned long long act_m = __ballot(state == ST_ACTIVE);
+        if (!feed.drained && ((int)__popcll(idle_m) >= kRefillMin || act_m == 0)) {
+            if (feedLanes(feed, A.ray_head, total, chunk, idle_m, state == ST_IDLE, idx)) {
+                const double* p = A.rays + (uint64_t)idx * kRayDoubles;
+                ray.o = mk3(p[0], p[1], p[2]);
+                ray.d = mk3(p[3], p[4], p[5]);
+                dist = p[6];
+                state = ST_RAY;
+            }
+        }
+        if (feed.drained && idle_m == ~0ULL) break;
+        if (act_m == 0) continue;
+        // (3) node steps
+        if (state == ST_ACTIVE && node >= 0) {
+            node = descend(S, node, rq, tmax, st, false, tc);
+            if (node == kTraversalDone) { A.ray_flag[idx] = 1; state = ST_IDLE; }
+        }
+        // (4) primitive tests
+        const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
+        if (leaf_m != 0) {
+            const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
+                leaf_wait = 0;
+                if (state == ST_ACTIVE && node < 0) {
+                    if (STATS) { tc->prims++; countWaveStep(tc->wave_prims); }
+                    if (testPrimBlocks(S, ray, S.prims[~node], c, dist)) { A.ray_flag[idx] = 0; state = ST_IDLE; }
+                    else {
+                        node = st.sp ? st.pop() : kTraversalDone;
+                        if (node == kTraversalDone) { A.ray_flag[idx] = 1; state = ST_IDLE; }
+                    }
+                }
+            }
         }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// The pairs whose shadow ray found nothing in the way, in queue order.
+__global__ __launch_bounds__(kBlock) void k_pair_compact(RenderArgs A) {
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    unsigned long long total = *A.ray_count;
+    if (total > A.pair_capacity) total = A.pair_capacity;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
+        const unsigned long long j = base + tid;
+        const bool vis = j < total && A.ray_flag[j] != 0;
+        const uint32_t pos = blockAppend(vis, A.vis_count, s_wave, &s_base);
+        if (vis) A.vis_pairs[pos] = (uint64_t)__double_as_longlong(A.rays[j * kRayDoubles + 7]);
+    }
 }
 
 // Adjacent lanes mostly hold pairs of one pixel-sample that land in the same pixel (the queue is in

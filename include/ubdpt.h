@@ -122,17 +122,12 @@ typedef struct ubdpt_options {
     uint32_t passes_in_flight;  /* passes rendered concurrently by one wavefront batch; 0 -> auto */
     uint32_t accel;             /* 0 = LBVH, 1 = linear scan over all primitives (reference order) */
     uint32_t collect_stats;     /* non-zero: count rays / vertices / traversal steps (slower) */
-    uint32_t pipeline;          /* 0 = default pipeline; 1..3 select variants kept for comparison */
-    uint32_t dense_threshold;   /* pipeline 3: lanes of a wave that must own an (s,t) pair to connect it in place; 0 -> 40 */
+    uint32_t pipeline;          /* 0 = wavefront pipeline (default); 1 = one lane per pixel-sample in the reference's
+                                   loop structure, kept as a cross-check of the default */
     uint32_t wavefront_depth;   /* bounces run as wavefront launches before the per-lane tail loop; 0 -> default, max 30 */
     uint32_t streams;           /* batches in flight on separate HIP streams; 0 -> default, max 16 */
     uint32_t batch_pixel_samples; /* non-zero and below one pass: a batch is this many pixels of one pass
                                      (overrides passes_in_flight); small batches keep the path vertices cache-resident */
-    uint32_t shadow_ray_budget; /* scenes too large for on-chip copies: traversal steps a shadow ray may take before it is
-                                   set aside and finished in a second launch with the other long rays (the result is the
-                                   same); 0 -> default, 0xffffffff -> one launch, no budget */
-    uint32_t closest_ray_budget; /* the same for the closest-hit rays of the subpaths (a deferred ray keeps its closest
-                                    candidate and is finished in a second launch); 0 -> default, 0xffffffff -> off */
     uint32_t pass_slots;        /* per-pass sum buffers held on the device besides the sum buffer (0: none, max 64);
                                    ubdpt_render_passes_separate keeps up to that many passes of a call apart */
     uint32_t traversal_stack_entries; /* entries of a ray's traversal stack; 0 -> 108 (the maximum: 12 on chip, 96 in

@@ -3,7 +3,7 @@
 C3: 100 k triangles, image texture, 1080p. C4: 2 M triangles, 1080p. C5: 100 k triangles, Lambertian / glossy /
 mirror / dielectric, 4K. The CPU oracle's scan over every face (the reference's algorithm, uapp/mesh.cpp:123-137)
 is not runnable at these sizes, so the full-size runs are checked through properties that do not depend on the
-size: the multi-GPU pass partition adds up, step budgets do not change the image, the tree agrees with the
+size: the multi-GPU pass partition adds up, the batch size does not change the image, the tree agrees with the
 device's linear scan, the image mean agrees with the oracle's tree mode (Mode B, itself asserted equal to the
 scan by tests/test_oracle_bvh.py) at a resolution it finishes in seconds. The material mix of C5 is compared
 with the oracle path by path on a 6 k-triangle version of the same scene."""
@@ -62,17 +62,19 @@ def test_full_size_render_properties(name, passes):
 
 
 @pytest.mark.parametrize("name", ["C3", "C4", "C5"])
-def test_step_budgets_do_not_change_the_image_at_full_triangle_count(name):
-    """Budgets of 2 steps (nearly every ray is finished in the second launch), the defaults and none: same image,
-    same counters. Full triangle count, an eighth of the resolution."""
+def test_batching_does_not_change_the_image_at_full_triangle_count(name):
+    """The persistent waves of the ray tracing kernels take their rays from queues in whatever order the hardware
+    runs them; which rays share a wave depends on the batch size and the number of streams. Batches of whole
+    passes on one stream against batches of 3000 pixels on three streams: same image, same counters. Full triangle
+    count, an eighth of the resolution."""
     scene, params, _ = config(name)
     small = reduced(params, 8)
     res = []
-    for shadow, closest in ((0xffffffff, 0xffffffff), (0, 0), (2, 2)):
+    for batch, streams in ((0, 1), (3000, 3)):
         opt = capi.Options()
         opt.collect_stats = 1
-        opt.shadow_ray_budget = shadow
-        opt.closest_ray_budget = closest
+        opt.batch_pixel_samples = batch
+        opt.streams = streams
         with capi.Context(scene, small, opt) as ctx:
             st, done = ctx.render_passes(0, 3, SEED)
             assert st == capi.SUCCESS and done == 3

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Traversal statistics per kernel (counting build): nodes and primitive tests per ray.
-  python tools/traversal_stats.py C3 [passes]"""
+"""Traversal statistics per kernel (counting build): nodes and primitive tests per ray, SIMD utilisation of the
+node step and of the primitive test.
+  python tools/traversal_stats.py C4 [passes]"""
 import importlib
 import os
 import sys
@@ -10,22 +11,24 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("bidirectional-pathtracing_amd")
 capi, scenes = pkg.capi, pkg.scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
-passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+passes = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 scene, params, _ = scenes.make_config(name)
-opt = capi.Options()
-opt.collect_stats = 1
-with capi.Context(scene, params, opt) as ctx:
-    ctx.render_passes(0, passes, 0x5EED)
-    s = ctx.stats()
-ps = s["pixel_samples"]
-print(name, "pixel-samples", ps, "closest/ps %.2f shadow/ps %.2f eye %.2f light %.2f conn/ps %.2f" % (
-    s["closest_hit_rays"] / ps, s["shadow_rays"] / ps, s["eye_vertices"] / ps, s["light_vertices"] / ps, s["connections"] / ps))
-for k in s["kernels"]:
-    rays = k["closest_hit_rays"] + k["shadow_rays"]
-    if rays:
-        print("%-16s rays %10d nodes/ray %6.2f prims/ray %5.2f ms/launch %.3f" % (
-            k["name"], rays, k["nodes_visited"] / rays, k["prims_tested"] / rays, k["ms"] / max(1, k["launches"])))
-for k in s["kernels"]:
-    if k["wave_node_steps"]:
-        print("%-16s SIMD utilisation: node step %.1f / 64 lanes, primitive test %.1f / 64 lanes" % (
-            k["name"], k["nodes_visited"] / k["wave_node_steps"], k["prims_tested"] / max(1, k["wave_prim_steps"])))
+for label in ("default",):
+    opt = capi.Options()
+    opt.collect_stats = 1
+    with capi.Context(scene, params, opt) as ctx:
+        ctx.render_passes(0, passes, 0x5EED)
+        s = ctx.stats()
+    ps = s["pixel_samples"]
+    print("==", name, label, "pixel-samples", ps, "closest/ps %.2f shadow/ps %.2f eye %.2f light %.2f conn/ps %.2f" % (
+        s["closest_hit_rays"] / ps, s["shadow_rays"] / ps, s["eye_vertices"] / ps, s["light_vertices"] / ps, s["connections"] / ps))
+    for k in s["kernels"]:
+        rays = k["closest_hit_rays"] + k["shadow_rays"]
+        if rays:
+            print("%-16s rays %10d nodes/ray %6.2f prims/ray %5.2f launches %d ms/launch %.3f max stack %d" % (
+                k["name"], rays, k["nodes_visited"] / rays, k["prims_tested"] / rays, k["launches"], k["ms"] / max(1, k["launches"]),
+                k["max_stack_entries"]))
+        if k["wave_node_steps"]:
+            print("%-16s wave node steps %d (%.1f / 64 lanes), wave primitive tests %d (%.1f / 64 lanes)" % (
+                k["name"], k["wave_node_steps"], k["nodes_visited"] / k["wave_node_steps"], k["wave_prim_steps"],
+                k["prims_tested"] / max(1, k["wave_prim_steps"])))
