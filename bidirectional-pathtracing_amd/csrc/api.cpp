@@ -144,6 +144,7 @@ struct ubdpt_context {
         double* d_rays = nullptr;        // shadow-ray queue (wavefront pipeline only)
         uint32_t* d_ray_count = nullptr;  // [0] rays in the queue, [1] claim position of the persistent waves
         uint8_t* d_ray_flag = nullptr;
+        uint64_t* d_ray_pairs = nullptr;
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
@@ -253,7 +254,7 @@ struct ubdpt_context {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
             hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
-            hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
+            hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_ray_pairs); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
         }
         hipFree(d_counters);
@@ -508,7 +509,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
         // (vertex records of both subpaths, overflow stack, pair / ray / visible-pair queues of 24 entries per path)
         uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8 +
-                            24ull * (8 + 8 + sizeof(double) * kRayDoubles + 1);
+                            24ull * (8 + 8 + 8 + sizeof(double) * kRayDoubles + 1);
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
             uint64_t target = 1ull << 22;  // measured: throughput still rises up to ~4 M pixel-samples per batch
@@ -563,6 +564,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             if (c->opt.pipeline == 0) {
                 ck(hipMalloc((void**)&b.d_rays, sizeof(double) * kRayDoubles * c->pair_capacity));
                 ck(hipMalloc((void**)&b.d_ray_flag, c->pair_capacity));
+                ck(hipMalloc((void**)&b.d_ray_pairs, sizeof(uint64_t) * c->pair_capacity));
             }
             ck(hipMalloc((void**)&b.d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
             ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
@@ -681,7 +683,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
         A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
         A.wf_hit = B.d_wf_hit; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
-        A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag;
+        A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag; A.ray_pairs = B.d_ray_pairs;
         double units = (double)A.E.n;
         // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
         // grid-stride kernels; 512 .. 16384 workgroups measured within 2 % of each other

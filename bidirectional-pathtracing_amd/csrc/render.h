@@ -30,7 +30,8 @@ struct RenderArgs {
     double* wf_hit;          // [2n][kHitDoubles]: d, u, v, (object | face << 32) of the closest hit found by k_wf_trace
     uint64_t* vis_pairs;     // connection pairs that passed the shadow ray
     uint32_t* vis_count;
-    double* rays;            // shadow-ray queue, kRayDoubles per ray: origin, direction, length, the pair (bits)
+    double* rays;            // shadow-ray queue, kRayDoubles per ray: origin, direction, length
+    uint64_t* ray_pairs;     // the pair each ray of the queue belongs to
     uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at
     uint32_t* ray_head;
     uint8_t* ray_flag;       // one per ray: 1 = nothing blocks it

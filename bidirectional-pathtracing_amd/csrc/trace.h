@@ -207,11 +207,12 @@ constexpr int32_t kTraversalDone = kEmptyChild;
 DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
     if (tb < ta) { float t = ta; ta = tb; tb = t; int32_t c = ca; ca = cb; cb = c; }
 }
-DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
-                    TraceCounters* tc) {
-    const BvhNode nd =
-        *reinterpret_cast<const BvhNode*>(reinterpret_cast<const char*>(S.nodes) + (size_t)node * S.node_stride);
+DEV BvhNode loadNode(const DScene& S, int32_t node) {
+    return *reinterpret_cast<const BvhNode*>(reinterpret_cast<const char*>(S.nodes) + (size_t)node * S.node_stride);
+}
+DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
     if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
+
     const float inf = __builtin_inff();
     float t0, t1, t2, t3;
     int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
@@ -230,6 +231,10 @@ DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, St
     if (tc && (uint32_t)st.sp > tc->max_stack) tc->max_stack = (uint32_t)st.sp;
     if (t0 < inf) return c0;
     return st.sp ? st.pop() : kTraversalDone;
+}
+DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
+                    TraceCounters* tc) {
+    return descendNode(loadNode(S, node), q, tmax, st, tc);
 }
 
 // UScene::intersectionPoint through the LBVH. Returns the lexicographically smallest (d, object, face).

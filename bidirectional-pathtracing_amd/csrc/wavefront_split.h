@@ -383,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_setup(RenderArgs A) {
             o[0] = lpos.x; o[1] = lpos.y; o[2] = lpos.z;
             o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
             o[6] = dist;
-            o[7] = __longlong_as_double((long long)p);
+            A.ray_pairs[pos] = p;
         }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
@@ -479,7 +479,9 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
-// The pairs whose shadow ray found nothing in the way, in queue order.
+// The pairs whose shadow ray found nothing in the way, in queue order. A lane looks at four consecutive rays (one
+// word of flags), so a workgroup appends the survivors of 1024 rays with one atomic: appends to one counter cost a
+// few nanoseconds each whatever their size, and there are tens of millions of rays.
 __global__ __launch_bounds__(kBlock) void k_pair_compact(RenderArgs A) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
@@ -487,11 +489,34 @@ __global__ __launch_bounds__(kBlock) void k_pair_compact(RenderArgs A) {
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
     unsigned long long total = *A.ray_count;
     if (total > A.pair_capacity) total = A.pair_capacity;
-    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
-        const unsigned long long j = base + tid;
-        const bool vis = j < total && A.ray_flag[j] != 0;
-        const uint32_t pos = blockAppend(vis, A.vis_count, s_wave, &s_base);
-        if (vis) A.vis_pairs[pos] = (uint64_t)__double_as_longlong(A.rays[j * kRayDoubles + 7]);
+    const unsigned long long words = (total + 3) / 4;
+    const uint32_t* flags = reinterpret_cast<const uint32_t*>(A.ray_flag);
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < words; base += nthreads) {
+        const unsigned long long w = base + tid;
+        uint32_t f = 0;
+        if (w < words) {
+            f = flags[w];
+            const unsigned long long left = total - 4 * w;  // rays this word covers (the last word may be partial)
+            if (left < 4) f &= (1u << (8 * (uint32_t)left)) - 1u;
+        }
+        const uint32_t n = (f & 1u) + ((f >> 8) & 1u) + ((f >> 16) & 1u) + ((f >> 24) & 1u);
+        // exclusive prefix of n over the workgroup
+        uint32_t incl = waveInclusiveScan(n);
+        if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t tot = 0;
+#pragma unroll
+            for (int k = 0; k < kBlock / 64; k++) tot += s_wave[k];
+            s_base = tot ? atomicAdd(A.vis_count, tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t pos = s_base + incl - n;
+        for (uint32_t k = 0; k < (tid >> 6); k++) pos += s_wave[k];
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if ((f >> (8 * k)) & 1u) A.vis_pairs[pos++] = A.ray_pairs[4 * w + k];
     }
 }
 
