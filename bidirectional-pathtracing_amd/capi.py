@@ -101,10 +101,10 @@ class Stats(C.Structure):
 EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
     "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
-    "ubdpt_read_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
+    "ubdpt_read_sum_device", "ubdpt_accumulate_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
     "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
-    "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
+    "ubdpt_get_image_size", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch",
 ]
 
@@ -165,6 +165,7 @@ def load_library(path=None):
     lib.ubdpt_enqueue_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
+    lib.ubdpt_accumulate_sum_device.argtypes = [vp, vp]
     lib.ubdpt_upload_sum.argtypes = [vp, vp]
     lib.ubdpt_image_rgb.argtypes = [vp, C.c_uint64, C.c_double, vp]
     lib.ubdpt_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
@@ -172,6 +173,7 @@ def load_library(path=None):
     lib.ubdpt_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
     lib.ubdpt_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     lib.ubdpt_get_camera_info.argtypes = [vp, vp, vp, vp]
+    lib.ubdpt_get_image_size.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ubdpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.ubdpt_reset_stats.argtypes = [vp]
     for n in ("ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch", "ubdpt_bsdf_scatter_batch"):

@@ -808,6 +808,17 @@ int ubdpt_read_sum_device(ubdpt_context* c, double* device_rgb) {
     return UBDPT_SUCCESS;
 }
 
+int ubdpt_accumulate_sum_device(ubdpt_context* c, double* device_rgb) {
+    if (!c || !device_rgb) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
+    launchInterleaveAdd(c->d_fb, c->npix, device_rgb, c->stream);
+    HIPCK(c, hipGetLastError());
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return UBDPT_SUCCESS;
+}
+
 // buffer 0 is the sum buffer, buffer 1 + k the per-pass buffer k
 static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add_into) {
     std::lock_guard<std::mutex> lock(c->mu);
@@ -1031,6 +1042,13 @@ int ubdpt_get_camera_info(ubdpt_context* c, double view[16], double inv_view[16]
     if (view) memcpy(view, &c->S.V, sizeof(double) * 16);
     if (inv_view) memcpy(inv_view, &c->S.invV, sizeof(double) * 16);
     if (image_plane_distance) *image_plane_distance = c->S.image_plane_distance;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_get_image_size(ubdpt_context* c, uint64_t* width, uint64_t* height) {
+    if (!c) return UBDPT_INVALID_ARG;
+    if (width) *width = c->params.img_res_x;
+    if (height) *height = c->params.img_res_y;
     return UBDPT_SUCCESS;
 }
 

@@ -73,6 +73,7 @@ hipError_t launchIntersectBatchNoAlloc(const DScene& S, const ubdpt_ray* rays, s
                                        uint32_t ovf_cap, unsigned long long* host_counters, hipStream_t s);
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
+void launchInterleaveAdd(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);
 // sums of the CIE 1931 fits over the three 123 nm bins (uengine/uconverter.cpp:31-76), computed once on the host
 struct RgbFit { d3 sumX, sumY, sumZ; };

@@ -735,6 +735,14 @@ __global__ void k_interleave(const double* fb, uint64_t npix, double* out) {
     out[3 * i + 1] = fb[npix + i];
     out[3 * i + 2] = fb[2 * npix + i];
 }
+// the same, added to what `out` already holds (per-GPU partial sums of contexts that share a device)
+__global__ void k_interleave_add(const double* fb, uint64_t npix, double* out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    out[3 * i] += fb[i];
+    out[3 * i + 1] += fb[npix + i];
+    out[3 * i + 2] += fb[2 * npix + i];
+}
 __global__ void k_deinterleave(const double* in, uint64_t npix, double* fb) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -855,6 +863,9 @@ void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_r
 }
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_interleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, out);
+}
+void launchInterleaveAdd(const double* fb, uint64_t npix, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_interleave_add, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, out);
 }
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s) {
     hipLaunchKernelGGL(k_deinterleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, in, npix, fb);

@@ -18,7 +18,8 @@ EXPORTS = ["uhip_engine_create", "uhip_engine_destroy", "uhip_engine_set_scene",
            "uhip_engine_render_pass", "uhip_engine_render_passes", "uhip_engine_stop", "uhip_engine_curr_pass",
            "uhip_engine_sum", "uhip_engine_image_rgb", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write",
            "uhip_ur_read", "uhip_scene_load_xml", "uhip_scene_ok", "uhip_scene_error", "uhip_scene_desc",
-           "uhip_scene_free"]
+           "uhip_scene_free", "uhip_multi_create", "uhip_multi_destroy", "uhip_multi_render_passes",
+           "uhip_multi_reduce_sum", "uhip_multi_clear", "uhip_reduce_sum_rccl"]
 
 _lib = None
 
@@ -59,8 +60,59 @@ def load_library():
         lib.uhip_scene_desc.argtypes = [vp]
         lib.uhip_scene_free.restype = None
         lib.uhip_scene_free.argtypes = [vp]
+        lib.uhip_multi_create.restype = vp
+        lib.uhip_multi_create.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.RenderParams), C.POINTER(capi.Options),
+                                          C.POINTER(C.c_int), C.c_size_t]
+        lib.uhip_multi_destroy.restype = None
+        lib.uhip_multi_destroy.argtypes = [vp]
+        lib.uhip_multi_render_passes.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_size_t)]
+        lib.uhip_multi_reduce_sum.argtypes = [vp, vp]
+        lib.uhip_multi_clear.restype = None
+        lib.uhip_multi_clear.argtypes = [vp]
+        lib.uhip_reduce_sum_rccl.argtypes = [vp, vp, C.c_int, vp, vp]
         _lib = lib
     return _lib
+
+
+class MultiGpu:
+    """uhip::MultiGpuRenderer: one context per entry of `devices` (a device may repeat), passes dealt round-robin,
+    per-device partial sums combined by an RCCL reduce inside the C++ host layer."""
+
+    def __init__(self, scene, params, devices, options=None):
+        self.lib = load_library()
+        self.scene, self.params = scene, params
+        self.width, self.height = int(params.img_res_x), int(params.img_res_y)
+        devs = (C.c_int * len(devices))(*devices)
+        opt = C.byref(options) if options is not None else None
+        self.h = self.lib.uhip_multi_create(C.byref(scene.desc), C.byref(params), opt, devs, len(devices))
+        if not self.h:
+            raise RuntimeError("uhip_multi_create failed")
+
+    def render_passes(self, first_pass, n, seed):
+        done = C.c_size_t(0)
+        st = self.lib.uhip_multi_render_passes(self.h, first_pass, n, seed, C.byref(done))
+        return st, done.value
+
+    def reduce_sum(self):
+        out = np.zeros((self.height, self.width, 3), np.float64)
+        st = self.lib.uhip_multi_reduce_sum(self.h, out.ctypes.data)
+        if st != 0:
+            raise RuntimeError(f"uhip_multi_reduce_sum: status {st}")
+        return out
+
+    def clear(self):
+        self.lib.uhip_multi_clear(self.h)
+
+    def close(self):
+        if self.h:
+            self.lib.uhip_multi_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class XmlScene:

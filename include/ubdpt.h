@@ -252,6 +252,9 @@ int ubdpt_request_stop(ubdpt_context* ctx);
 int ubdpt_read_sum(ubdpt_context* ctx, double* rgb, int add_into);
 /* Same data, but written to DEVICE memory owned by the caller (e.g. a buffer handed to an RCCL reduce). */
 int ubdpt_read_sum_device(ubdpt_context* ctx, double* device_rgb);
+/* device_rgb[i] += device sum: the step before the inter-GPU reduce when several contexts share one device (the
+ * reference's counterpart is the += of every thread into the one pixel buffer, uengine/ubdptrenderer.cpp:144,153). */
+int ubdpt_accumulate_sum_device(ubdpt_context* ctx, double* device_rgb);
 /* Replaces the device sum (resume from a .ur file, uengine/uengine.cpp:107-116). NULL clears it. */
 int ubdpt_upload_sum(ubdpt_context* ctx, const double* rgb);
 
@@ -305,6 +308,9 @@ int ubdpt_get_object_info(ubdpt_context* ctx, uint32_t object, double invW[16], 
                           double* probability, double bounding_sphere[16]);
 /* View matrix and image-plane distance the renderer snapshots (uengine/ubdptrenderer.cpp:11-14). */
 int ubdpt_get_camera_info(ubdpt_context* ctx, double view[16], double inv_view[16], double* image_plane_distance);
+
+/* img_res_x / img_res_y the context was created with (URenderParameters, uengine/uutils.h:11-20): the size of the sum buffer. */
+int ubdpt_get_image_size(ubdpt_context* ctx, uint64_t* width, uint64_t* height);
 
 int ubdpt_get_stats(ubdpt_context* ctx, ubdpt_stats* out);
 int ubdpt_reset_stats(ubdpt_context* ctx);
