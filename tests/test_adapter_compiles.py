@@ -1,0 +1,32 @@
+"""The URenderer subclass a reference maintainer adds (host/reference_adapter/ubdpthiprenderer.h) is syntax-checked
+against the reference's OWN interface headers. This pins signatures (uengine/urenderer.h:10-16, the layout of
+URenderParameters, the UBuffer2D / UScene types), not numbers. GLM, which those headers include, is not
+available: tests/glm_decl_stub declares the few type names they mention and computes nothing.
+Runs only where the reference tree is present (the build container)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/uengine"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "urenderer.h")), reason="reference tree not present")
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_adapter_compiles_against_the_reference_interface():
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra",
+           "-I", os.path.join(ROOT, "tests", "glm_decl_stub"), "-I", REF, "-I", os.path.join(ROOT, "include"),
+           "-I", os.path.join(ROOT, "bidirectional-pathtracing_amd", "host", "reference_adapter"),
+           os.path.join(ROOT, "tests", "adapter_check.cpp")]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+
+
+def test_integration_notes_show_the_adapter_that_is_checked():
+    """INTEGRATION.md quotes the adapter; the quoted class body must be the checked file's."""
+    src = open(os.path.join(ROOT, "bidirectional-pathtracing_amd", "host", "reference_adapter", "ubdpthiprenderer.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    body = src[src.index("class UBDPTHipRenderer"):src.index("#endif // UBDPTHIPRENDERER_H")].strip()
+    assert body in doc
