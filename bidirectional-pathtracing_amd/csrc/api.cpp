@@ -101,6 +101,7 @@ struct ubdpt_context {
     float* d_face_pos = nullptr;
     FaceAttr* d_face_attr = nullptr;
     double* d_face_prob = nullptr;
+    double* d_face_cdf = nullptr;
     DTexture* d_textures = nullptr;
     uint8_t* d_texels = nullptr;
     BvhNode* d_nodes = nullptr;
@@ -246,7 +247,7 @@ struct ubdpt_context {
         for (auto& f : fences) for (auto& e : f) hipEventDestroy(e);
         if (clear_ev) hipEventDestroy(clear_ev);
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
-        hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob);
+        hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob); hipFree(d_face_cdf);
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         if (h_staging) { hipHostFree(h_staging); h_staging = nullptr; }
         if (h_noalloc_counters) { hipHostFree(h_noalloc_counters); h_noalloc_counters = nullptr; }
@@ -279,6 +280,7 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
     std::vector<float> face_pos(9 * sd->num_faces);
     std::vector<FaceAttr> face_attr(sd->num_faces);
     std::vector<double> face_prob(sd->num_faces, 0.0);
+    std::vector<double> face_cdf(sd->num_faces, 0.0);
     std::vector<DTexture> textures(sd->num_textures);
     std::vector<Prim> prims;
 
@@ -335,6 +337,8 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
                 total_area += a;
             }
             for (uint64_t f = 0; f < o.num_faces; f++) face_prob[o.first_face + f] = face_prob[o.first_face + f] / total_area;
+            double run = 0;
+            for (uint64_t f = 0; f < o.num_faces; f++) { face_cdf[o.first_face + f] = run; run += face_prob[o.first_face + f]; }
             o.bsphere = boundingSphere(V, o.first_face, o.num_faces);
             for (uint64_t f = 0; f < o.num_faces; f++) {
                 Prim p;
@@ -381,6 +385,7 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
     HIPCK(c, upload(&c->d_face_pos, face_pos));
     HIPCK(c, upload(&c->d_face_attr, face_attr));
     HIPCK(c, upload(&c->d_face_prob, face_prob));
+    HIPCK(c, upload(&c->d_face_cdf, face_cdf));
     HIPCK(c, upload(&c->d_textures, textures));
     {
         std::vector<uint8_t> tex(sd->texels, sd->texels + (sd->texels ? sd->num_texel_bytes : 0));
@@ -397,7 +402,7 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
 
     DScene& S = c->S;
     S.objects = c->d_objects; S.emitters = c->d_emitters; S.face_pos = c->d_face_pos; S.face_attr = c->d_face_attr;
-    S.face_prob = c->d_face_prob; S.textures = c->d_textures; S.texels = c->d_texels;
+    S.face_prob = c->d_face_prob; S.face_cdf = c->d_face_cdf; S.textures = c->d_textures; S.texels = c->d_texels;
     S.nodes = c->d_nodes; S.prims = c->d_prims;
     S.num_objects = sd->num_objects; S.num_emitters = (uint32_t)emitters.size(); S.num_prims = (uint32_t)prims.size();
     S.accel = c->opt.accel; S.num_faces = sd->num_faces;

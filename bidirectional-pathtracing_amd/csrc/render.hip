@@ -252,19 +252,34 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
 // ---------------------------------------------------------------------------------------------------
 // light subpath: computeLightSubpath (ubdptrenderer.cpp:409-594); emitter point = uapp/emitter.cpp:19-30
 // ---------------------------------------------------------------------------------------------------
+constexpr uint64_t kLinearCdfFaces = 64;  // emitter meshes up to this size are sampled with the reference's linear walk
 DEV void emitterRandomPoint(const DScene& S, const DObject& e, const Rng& rng, d3& pos, d3& Ng, d3& Ns, d3& Ts, d3& Bs) {
     if (e.kind == 0) {  // uapp/implicitsphere.cpp:32-38
         Ns = Ng = sampleUnitSphereUniform(rng(DIM_POINT_A), rng(DIM_POINT_B));
         pos = Ng;
         Ts = -Ns + mk3(0, 0, 1.0 / Ns.z);
         Bs = cross(Ns, Ts);
-    } else {  // uapp/mesh.cpp:206-232: linear walk over the face probabilities
+    } else {  // uapp/mesh.cpp:206-232: walk over the face probabilities until the uniform number is used up
         double r = rng(DIM_POINT_A);
         uint64_t f = 0;
-        for (; f + 1 < e.num_faces; f++) {
-            double p = S.face_prob[e.first_face + f];
-            if (r < p) break;
-            r -= p;
+        if (e.num_faces <= kLinearCdfFaces) {  // the reference's own walk, subtraction by subtraction
+            for (; f + 1 < e.num_faces; f++) {
+                double p = S.face_prob[e.first_face + f];
+                if (r < p) break;
+                r -= p;
+            }
+        } else {
+            // Large meshes: the face whose range of the running sum holds r, by bisection (the walk is O(#faces) per
+            // light subpath). The walk subtracts face by face and the table adds face by face, so within a few
+            // hundred ulps of a boundary between two faces the two can pick different neighbours: a fraction of
+            // about 1e-13 * #faces of the samples, each moving to an adjacent face of the same mesh.
+            const double* cdf = S.face_cdf + e.first_face;
+            uint64_t lo = 0, hi = e.num_faces - 1;  // the answer is in [lo, hi]; the last face takes what rounding leaves over
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi + 1) >> 1;
+                if (cdf[mid] <= r) lo = mid; else hi = mid - 1;
+            }
+            f = lo;
         }
         const float* p = S.face_pos + 9 * (e.first_face + f);
         const FaceAttr& fa = S.face_attr[e.first_face + f];

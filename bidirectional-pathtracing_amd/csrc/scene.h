@@ -74,6 +74,7 @@ struct DScene {
     const float* face_pos;    // [num_faces][9], object order (linear-scan accelerator + winning-face reload)
     const FaceAttr* face_attr;
     const double* face_prob;  // uapp/mesh.cpp:88-106
+    const double* face_cdf;   // per mesh: sum of face_prob over the faces before this one (running fp64 sum in face order)
     const DTexture* textures;
     const uint8_t* texels;
     const BvhNode* nodes;

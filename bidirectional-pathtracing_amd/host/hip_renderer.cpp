@@ -172,7 +172,10 @@ Result HipEngine::newRendering(const RenderParameters& params, RendererType type
 
 Result HipEngine::saveRendering(const std::string& filename) const {
     if (!m_buffers[m_read]) return Result::UError;
-    return writeUr(filename, m_curr_pass, m_params, m_type, m_buffers[m_read]->ptr());
+    // The file records WHAT was rendered (the BDPT estimator, sums of passes), not which implementation rendered it:
+    // the type written is always BDPT (0), the only value the unmodified reference accepts (uengine.cpp:123-130; it has
+    // overwritten its state by the time it rejects an unknown type), so a checkpoint moves between the two freely.
+    return writeUr(filename, m_curr_pass, m_params, RendererType::BDPT, m_buffers[m_read]->ptr());
 }
 
 Result HipEngine::loadRendering(const std::string& filename, RenderParameters& params, RendererType& type, size_t& curr_pass) {

@@ -583,3 +583,32 @@ def test_traversal_stack_overflow_is_reported_not_hidden():
                 assert st == capi.SUCCESS and done == 1
     assert np.array_equal(res[0]["face"], res[1]["face"]) and (res[0]["face"] == 0).all()
     assert np.array_equal(res[0]["d"].view(np.uint64), res[1]["d"].view(np.uint64))
+
+
+def test_large_mesh_emitter_is_sampled_like_the_reference_walk(oracle_mod):
+    """An emitter mesh of 3000 faces: the reference picks the face by walking the face probabilities
+    (uapp/mesh.cpp:206-232, O(#faces) per light subpath), the backend bisects a table of running sums for meshes of
+    more than 64 faces. The two can only differ within rounding of a boundary between two faces, so the image
+    must match the oracle's path by path like every other scene."""
+    b = scenes.SceneBuilder(scenes.make_camera((0, 0, -3.4), (0, 0, 0), 0.69, 1.0))
+    scenes._cornell_shell(b)
+    lamp = scenes.displaced_sphere(3000, seed=9, amp=0.1)
+    b.mesh(lamp, scenes.mesh_transform((0.3, 0.2, 0.1), 0.5, (0, 1, 0), (0.15, 0.1, 0.15)), capi.MAT_LATEX_PAINT,
+           b.color((0.8, 0.8, 0.8)), power=(6, 5, 4))
+    scene = b.build()
+    w = h = 48
+    passes = 3
+    params = scenes.make_params(w, h)
+    opt = capi.Options()
+    opt.collect_stats = 1
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        got = ctx.read_sum()
+        s = ctx.stats()
+    ref, cn = oracle_mod.Oracle(scene, params, 32).render_passes(0, passes, SEED, num_threads=8, counters=True)
+    bad, rm = image_agreement(got, ref, passes)
+    print(f"mesh emitter: {bad * 100:.3f} % of pixels off by > 1e-9")
+    assert bad <= 0.005 and rm <= 2e-3, (bad, rm)
+    for k in ("eye_vertices", "light_vertices", "connections", "splats"):
+        assert abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2, (k, s[k], cn[k])

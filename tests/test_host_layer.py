@@ -119,6 +119,36 @@ def test_engine_pass_by_pass_across_windows(pass_slots):
 
 
 @pytest.mark.gpu
+def test_engine_pass_windows_match_the_oracle_path_by_path():
+    """The reference-shaped renderPass (one pass per call, served from windows rendered ahead through
+    ubdpt_enqueue_passes_separate / ubdpt_read_sum_slot) against the CPU oracle on the same seed: at most 0.5 % of
+    the pixels may deviate by more than 1e-9 relative. Also: a checkpoint saved with the default renderer type
+    carries type 0, the only one the unmodified reference loads (uengine.cpp:123-130)."""
+    import oracle_py
+    import tempfile, os
+    sc, params = c2(40, 40)
+    passes = 5
+    opt = capi.Options()
+    opt.pass_slots = 4
+    with hostapi.Engine(sc, options=opt) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        for k in range(passes):
+            assert eng.render_pass() == hostapi.USUCCESS
+        got = eng.sum()
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "x.ur")
+            assert eng.save(path) == hostapi.USUCCESS
+            st, cp, p2, t, s2 = hostapi.ur_read(path)
+            assert st == hostapi.USUCCESS and cp == passes and t == hostapi.BDPT and np.array_equal(s2, got)
+    ref = oracle_py.Oracle(sc, params, 32).render_passes(0, passes, SEED, num_threads=4)
+    g, r = got / passes, ref / passes
+    err = np.abs(g - r) / np.maximum(np.abs(r), 1e-3)
+    bad = float(np.any(err > 1e-9, axis=2).mean())
+    print(f"engine pass windows vs oracle: {bad * 100:.3f} % of pixels off by > 1e-9")
+    assert np.isfinite(got).all() and bad <= 0.005, bad
+
+
+@pytest.mark.gpu
 def test_engine_save_load_resume(tmp_path):
     sc, params = c2(32, 32)
     path = str(tmp_path / "r.ur")
@@ -130,7 +160,7 @@ def test_engine_save_load_resume(tmp_path):
         straight = eng.sum()
     with hostapi.Engine(sc) as eng:
         st, p, t, cp = eng.load(path)
-        assert st == hostapi.USUCCESS and cp == 2 and t == hostapi.BDPT_HIP and p.img_res_x == 32
+        assert st == hostapi.USUCCESS and cp == 2 and t == hostapi.BDPT and p.img_res_x == 32  # files always carry type 0
         assert eng.curr_pass == 2
         assert eng.render_pass() == hostapi.USUCCESS                    # resume pass by pass ...
         assert eng.render_passes(2) == hostapi.USUCCESS                 # ... and batched
