@@ -71,6 +71,11 @@ HIT_DTYPE = np.dtype([("hit", "<i4"), ("object", "<i4"), ("face", "<i8"), ("d", 
 SEGMENT_DTYPE = np.dtype([("p0", "<f8", 3), ("p1", "<f8", 3)])
 BSDF_QUERY_DTYPE = np.dtype([("lobe", "<i4"), ("reserved", "<i4"), ("eta", "<f8"), ("tex", "<f8", 3),
                              ("frame", "<f8", 12), ("wi", "<f8", 3), ("wo", "<f8", 3), ("u1", "<f8"), ("u2", "<f8")])
+PATH_VERTEX_DTYPE = np.dtype([("pos", "<f8", 3), ("Ng", "<f8", 3), ("Ns", "<f8", 3), ("Ts", "<f8", 3), ("Bs", "<f8", 3),
+                              ("tex_u", "<f8"), ("tex_v", "<f8"), ("a", "<f8", 3), ("p_light_A", "<f8"),
+                              ("p_eye_A", "<f8"), ("object", "<i4"), ("lobe", "<i4"), ("specular", "<i4"),
+                              ("reserved", "<i4")])
+CONNECTION_DTYPE = np.dtype([("connected", "<i4"), ("reserved", "<i4"), ("c", "<f8", 3), ("w", "<f8")])
 BSDF_RESULT_DTYPE = np.dtype([("f", "<f8", 3), ("pdf", "<f8"), ("dir", "<f8", 3), ("ok", "<i4"), ("specular", "<i4")])
 
 
@@ -105,7 +110,7 @@ EXPORTS = [
     "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_image_size", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
-    "ubdpt_bsdf_scatter_batch",
+    "ubdpt_bsdf_scatter_batch", "ubdpt_connection_probe",
 ]
 
 
@@ -176,6 +181,7 @@ def load_library(path=None):
     lib.ubdpt_get_image_size.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ubdpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.ubdpt_reset_stats.argtypes = [vp]
+    lib.ubdpt_connection_probe.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
     for n in ("ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch", "ubdpt_bsdf_scatter_batch"):
         getattr(lib, n).argtypes = [vp, vp, C.c_size_t, vp]
     for n in EXPORTS:
@@ -333,6 +339,16 @@ class Context:
 
     def reset_stats(self):
         _check(self.lib.ubdpt_reset_stats(self.handle), "ubdpt_reset_stats")
+
+    def connection_probe(self, eye, light):
+        """Device connectionFactor / weight for every (s, t) and s0sample for every eye prefix of one pair of
+        subpaths (arrays of PATH_VERTEX_DTYPE): (connections [n_light, n_eye], s0 [n_eye, 3])."""
+        eye = np.ascontiguousarray(eye, PATH_VERTEX_DTYPE); light = np.ascontiguousarray(light, PATH_VERTEX_DTYPE)
+        out = np.zeros((light.shape[0], eye.shape[0]), CONNECTION_DTYPE)
+        s0 = np.zeros((eye.shape[0], 3))
+        _check(self.lib.ubdpt_connection_probe(self.handle, eye.ctypes.data, eye.shape[0], light.ctypes.data,
+                                               light.shape[0], out.ctypes.data, s0.ctypes.data), "ubdpt_connection_probe")
+        return out, s0
 
     def _bsdf(self, fn, q):
         q = np.ascontiguousarray(q, BSDF_QUERY_DTYPE)

@@ -1009,6 +1009,45 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
     return st;
 }
 
+int ubdpt_connection_probe(ubdpt_context* c, const ubdpt_path_vertex* eye, uint32_t n_eye, const ubdpt_path_vertex* light,
+                           uint32_t n_light, ubdpt_connection* out, double* s0) {
+    if (!c || !eye || !light || !out || n_eye == 0 || n_light == 0 || n_eye > 255 || n_light > 255) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
+    { int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
+    const size_t pairs = (size_t)n_eye * n_light;
+    // one allocation: vertex input (eye, light), the two one-path stores, their count words, the outputs
+    const size_t in_bytes = sizeof(ubdpt_path_vertex) * ((size_t)n_eye + n_light);
+    const size_t store_bytes = sizeof(double) * kVertexDoubles * ((size_t)n_eye + n_light);
+    const size_t out_bytes = sizeof(ubdpt_connection) * pairs, s0_bytes = sizeof(double) * 3 * n_eye;
+    char* d = nullptr;
+    HIPCK(c, hipMalloc((void**)&d, in_bytes + store_bytes + 64 + out_bytes + s0_bytes));
+    ubdpt_path_vertex* d_eye = reinterpret_cast<ubdpt_path_vertex*>(d);
+    ubdpt_path_vertex* d_light = d_eye + n_eye;
+    PathStore E{}, L{};
+    E.v = reinterpret_cast<double*>(d + in_bytes); E.n = 1; E.maxv = n_eye; E.count_stride = 1;
+    L.v = E.v + (size_t)kVertexDoubles * n_eye; L.n = 1; L.maxv = n_light; L.count_stride = 1;
+    E.count = reinterpret_cast<uint32_t*>(d + in_bytes + store_bytes);
+    L.count = E.count + 8;
+    ubdpt_connection* d_out = reinterpret_cast<ubdpt_connection*>(d + in_bytes + store_bytes + 64);
+    double* d_s0 = reinterpret_cast<double*>(d + in_bytes + store_bytes + 64 + out_bytes);
+    hipError_t e = hipMemcpyAsync(d_eye, eye, sizeof(ubdpt_path_vertex) * n_eye, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_light, light, sizeof(ubdpt_path_vertex) * n_light, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        launchConnectionProbe(c->S, d_eye, n_eye, d_light, n_light, E, L, d_out, d_s0, c->lanes[0].d_ovf, c->ovf_threads,
+                              c->ovf_cap, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && s0) e = hipMemcpyAsync(s0, d_s0, s0_bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d);
+    if (e != hipSuccess) { c->last_hip = e; return UBDPT_HIP_ERROR; }
+    int st = fetchCounters(c);
+    if (st == UBDPT_SUCCESS) st = reportStackOverflows(c);
+    return st;
+}
+
 static int bsdfBatch(ubdpt_context* c, int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r) {
     if (!c || (n && (!q || !r))) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);

@@ -71,6 +71,10 @@ constexpr uint64_t kNoAllocLanes = 32768;
 hipError_t noAllocScratch(int device, void** out);  // device must be current; resolves the array's address once per device
 hipError_t launchIntersectBatchNoAlloc(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, void* scratch_ptr,
                                        uint32_t ovf_cap, unsigned long long* host_counters, hipStream_t s);
+// stores E / L: one path (n = 1), maxv >= the vertex counts, dense count words
+void launchConnectionProbe(const DScene& S, const ubdpt_path_vertex* eye, uint32_t n_eye, const ubdpt_path_vertex* light,
+                           uint32_t n_light, PathStore E, PathStore L, ubdpt_connection* out, double* s0, int32_t* ovf,
+                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s);
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchInterleaveAdd(const double* fb, uint64_t npix, double* out, hipStream_t s);

@@ -499,35 +499,40 @@ DEV uint32_t waveInclusiveScan(uint32_t v) {
     return v;
 }
 
-// Second half: connection factor and MIS weight (no ray is traced here). Returns the contribution and the
-// pixel it belongs to; false when the pair contributes nothing.
-template <bool STATS>
-DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally& ty, uint64_t& pixel, d3& value) {
-    const DScene& S = A.S;
-    const PathStore& E = A.E;
-    const PathStore& L = A.L;
-    uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
-    // every load whose address depends on (i, s, t) only is issued here, before the first use of any of them
-    // (the positions before the end vertices exist only for s, t > 1 and are only used then; slot 0 is read otherwise)
-    ConnVertex vl, ve;
+// Connection factor c and MIS weight w of the pair (s, t) of pixel-sample i, after the tests that reject without
+// arithmetic (specular ends, t = 1 projection, shadow ray): connectionFactor from its cosine tests on
+// (ubdptrenderer.cpp:612-690) and weight (:779-844). Every load whose address depends on (i, s, t) only is issued
+// before the first use of any of them (the positions before the end vertices exist only for s, t > 1 and are only
+// used then; slot 0 is read otherwise). a = throughput product of the two end vertices. False: contributes nothing.
+DEV bool pairConnection(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, uint32_t s, uint32_t t,
+                        ConnVertex& vl, ConnVertex& ve, d3& c, double& w) {
     loadConn(L, s - 1, i, vl);
     loadConnEye(S, E, t - 1, i, ve);
     d3 lprev = L.ld3(F_POS, s > 1 ? s - 2 : 0, i);
     d3 eprev = E.ld3(F_POS, t > 1 ? t - 2 : 0, i);
     WalkAhead wa;
     loadWalkAhead(L, E, i, s, t, wa);
+    if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN))
+        return connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, wa, c, w);
+    if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return false;
+    w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
+    return true;
+}
+
+// Second half of a connection (no ray is traced here). Returns the contribution and the pixel it belongs to;
+// false when the pair contributes nothing.
+template <bool STATS>
+DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally& ty, uint64_t& pixel, d3& value) {
+    const DScene& S = A.S;
+    ConnVertex vl, ve;
+    d3 c;
+    double w;
+    const bool ok = pairConnection(S, A.L, A.E, i, s, t, vl, ve, c, w);
     uint32_t tx = 0, tyy = 0;
     if (t == 1) {
         if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) return false;
     }
-    d3 c;
-    double w;
-    if ((s == 1 || vl.lobe == LOBE_LAMBERTIAN) && (t == 1 || ve.lobe == LOBE_LAMBERTIAN)) {
-        if (!connectLambert(S, L, E, i, vl, ve, s, t, lprev, eprev, wa, c, w)) return false;
-    } else {
-        if (!connectionFactorTail(S, vl, ve, s, t, lprev, eprev, c)) return false;
-        w = misWeight(S, L, E, i, vl, ve, s, t, lprev, eprev);
-    }
+    if (!ok) return false;
     if (STATS) { ty.conn++; ty.fb++; }
     if (t == 1) {
         if (STATS) ty.splat++;
@@ -713,6 +718,75 @@ __global__ __launch_bounds__(kBlock) void k_visibility_batch(DScene S, const ubd
     if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
 }
 
+// ---- connection probe: the connection code of the rendering kernels on one pair of subpaths handed in as arrays ----
+// Fills the records of a one-path store from UPathVertex-shaped input (texture colour looked up from the
+// vertex's texture coordinates, as shading does when it stores a vertex).
+__global__ void k_probe_fill(DScene S, const ubdpt_path_vertex* in, uint32_t n, PathStore P) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) {
+        uint32_t m = n;
+        for (uint32_t j = 0; j < n && j < kMaskedVertices; j++) m |= specularBit(j, in[j].specular != 0);
+        P.setMeta(0, m);
+    }
+    if (k >= n) return;
+    const ubdpt_path_vertex& v = in[k];
+    Vertex x;
+    x.sp.pos = mk3(v.pos[0], v.pos[1], v.pos[2]); x.sp.Ng = mk3(v.Ng[0], v.Ng[1], v.Ng[2]);
+    x.sp.Ns = mk3(v.Ns[0], v.Ns[1], v.Ns[2]); x.sp.Ts = mk3(v.Ts[0], v.Ts[1], v.Ts[2]); x.sp.Bs = mk3(v.Bs[0], v.Bs[1], v.Bs[2]);
+    x.sp.tex_u = v.tex_u; x.sp.tex_v = v.tex_v; x.sp.object = v.object; x.sp.lobe = v.lobe; x.sp.face = 0;
+    x.a = mk3(v.a[0], v.a[1], v.a[2]);
+    x.tex = v.object >= 0 ? textureSample(S, S.objects[v.object].texture, v.tex_u, v.tex_v) : mk3(0, 0, 0);
+    x.specular = false;  // store the whole record; the flag follows
+    x.p_light_A = v.p_light_A; x.p_eye_A = v.p_eye_A;
+    storeVertex(P, k, 0, x);
+    P.setObjFlags(k, 0, v.object, ((v.lobe + 1) & 0xff) | (v.specular ? 0x100 : 0));
+}
+
+__global__ __launch_bounds__(kBlock) void k_connection_probe(DScene S, PathStore E, PathStore L, uint32_t n_eye, uint32_t n_light,
+                                                            ubdpt_connection* out, double* s0, int32_t* ovf, uint64_t ovf_stride,
+                                                            uint32_t ovf_cap, unsigned long long* counters) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid, ovf_cap);
+    Tally ty;
+    const uint32_t pairs = n_eye * n_light;
+    if (gid < pairs) {
+        const uint32_t s = (uint32_t)gid / n_eye + 1, t = (uint32_t)gid % n_eye + 1;
+        ubdpt_connection o;
+        o.connected = 0; o.reserved = 0; o.c[0] = o.c[1] = o.c[2] = 0; o.w = 0;
+        const uint32_t mE = E.meta(0), mL = L.meta(0);
+        // connectionFactor's order: specular ends (:604), visibility (:609), then the rest
+        if (L.connectable(mL, s - 1, 0) && E.connectable(mE, t - 1, 0) &&
+            visible<true>(S, L.ld3(F_POS, s - 1, 0), E.ld3(F_POS, t - 1, 0), st, ty)) {
+            ConnVertex vl, ve;
+            d3 c;
+            double w;
+            if (pairConnection(S, L, E, 0, s, t, vl, ve, c, w)) {
+                o.connected = 1; o.c[0] = c.x; o.c[1] = c.y; o.c[2] = c.z; o.w = w;
+            }
+        }
+        out[gid] = o;
+    } else if (s0 && gid - pairs < n_eye) {
+        const uint32_t t = (uint32_t)(gid - pairs);
+        d3 v = mk3(0, 0, 0);
+        if (t >= 1) {
+            ConnVertex cv;
+            loadConn(E, t, 0, cv);
+            Vertex ev;
+            ev.sp.object = cv.object; ev.sp.pos = cv.pos; ev.sp.Ns = cv.Ns; ev.a = cv.a; ev.p_eye_A = cv.p_eye_A;
+            Tail cur;
+            cur.pos = E.ld3(F_POS, t - 1, 0);
+            cur.Ns = t - 1 == 0 ? lensNormal(S) : E.ld3(F_NS, t - 1, 0);
+            cur.p_eye_A = E.ld(F_PE, t - 1, 0);
+            cur.specular = E.specular(t - 1, 0);
+            const bool prev_specular = t >= 2 && E.specular(t - 2, 0);
+            v = s0sample(S, E, 0, t, cur, prev_specular, ev);
+        }
+        s0[3 * t] = v.x; s0[3 * t + 1] = v.y; s0[3 * t + 2] = v.z;
+    }
+    if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
+}
+
 __global__ __launch_bounds__(kBlock) void k_bsdf_batch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* out) {
     uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     if (gid >= n) return;
@@ -871,6 +945,15 @@ void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n,
                            uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
     if (n == 0) return;
     hipLaunchKernelGGL(k_visibility_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, ovf_cap, counters);
+}
+void launchConnectionProbe(const DScene& S, const ubdpt_path_vertex* eye, uint32_t n_eye, const ubdpt_path_vertex* light,
+                           uint32_t n_light, PathStore E, PathStore L, ubdpt_connection* out, double* s0, int32_t* ovf,
+                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
+    hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(kBlock), 0, s, S, eye, n_eye, E);
+    hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(kBlock), 0, s, S, light, n_light, L);
+    const uint64_t threads = (uint64_t)n_eye * n_light + n_eye;
+    hipLaunchKernelGGL(k_connection_probe, dim3(gridFor(threads)), dim3(kBlock), 0, s, S, E, L, n_eye, n_light, out, s0, ovf,
+                       ovf_stride, ovf_cap, counters);
 }
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s) {
     if (n == 0) return;

@@ -340,6 +340,36 @@ typedef struct ubdpt_bsdf_result {
     int32_t specular;
 } ubdpt_bsdf_result;
 
+/*
+ * Connection probe: UBDPTRenderer::connectionFactor (uengine/ubdptrenderer.cpp:596-691), weight (:779-844, with
+ * p_sp1 :693-735 and p_sm1 :737-777) and s0sample (:156-222) evaluated by the device code of the rendering kernels
+ * on ONE pair of subpaths handed in as vertex arrays (UPathVertex, uengine/ubdptrenderer.h:9-24: world-space surface
+ * point, throughput a, the two area pdfs, the specular flag; object = -1 for the lens vertex).
+ * out[(s-1) * n_eye + (t-1)] for s = 1..n_light, t = 1..n_eye: connected = connectionFactor's return value (0 when an
+ * end is specular, the ends do not see each other, or a cosine / BSDF test fails), c = the connection factor,
+ * w = the MIS weight (only meaningful when connected). s0[3 * t .. 3 * t + 2] for t = 1..n_eye-1 = s0sample with
+ * eye[t] as the vertex that hit an emitter and eye[0..t-1] as the subpath (zero when eye[t] is not on an emitter);
+ * s0 may be NULL. At most 255 vertices per subpath.
+ */
+typedef struct ubdpt_path_vertex {
+    double  pos[3], Ng[3], Ns[3], Ts[3], Bs[3];
+    double  tex_u, tex_v;
+    double  a[3];
+    double  p_light_A, p_eye_A;
+    int32_t object;     /* -1 for the lens vertex */
+    int32_t lobe;       /* UBDPT_LOBE_* */
+    int32_t specular;
+    int32_t reserved;
+} ubdpt_path_vertex;
+typedef struct ubdpt_connection {
+    int32_t connected;
+    int32_t reserved;
+    double  c[3];
+    double  w;
+} ubdpt_connection;
+int ubdpt_connection_probe(ubdpt_context* ctx, const ubdpt_path_vertex* eye, uint32_t n_eye,
+                           const ubdpt_path_vertex* light, uint32_t n_light, ubdpt_connection* out, double* s0);
+
 int ubdpt_bsdf_eval_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);
 int ubdpt_bsdf_pdf_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);
 int ubdpt_bsdf_scatter_batch(ubdpt_context* ctx, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r);

@@ -1287,6 +1287,17 @@ dmat4 mat_from(const double m[16]) {
 }
 void mat_to(const dmat4& m, double out[16]) { std::memcpy(out, &m, sizeof(double) * 16); }
 
+PathVertex vertex_from(const oracle_vertex& o) {
+    auto get = [](const double* d) { return dvec3{d[0], d[1], d[2]}; };
+    PathVertex v;
+    v.sp.pos = get(o.pos); v.sp.Ng = get(o.Ng); v.sp.Ns = get(o.Ns); v.sp.Ts = get(o.Ts); v.sp.Bs = get(o.Bs);
+    v.sp.tex_u = o.tex_u; v.sp.tex_v = o.tex_v;
+    v.a = get(o.a);
+    v.p_light_A = o.p_light_A; v.p_eye_A = o.p_eye_A;
+    v.sp.object = o.object; v.sp.lobe = o.lobe; v.specular = o.specular != 0;
+    return v;
+}
+
 void fill_vertex(const PathVertex& v, oracle_vertex& o) {
     auto put = [](double* d, dvec3 s) { d[0] = s.x; d[1] = s.y; d[2] = s.z; };
     put(o.pos, v.sp.pos); put(o.Ng, v.sp.Ng); put(o.Ns, v.sp.Ns); put(o.Ts, v.sp.Ts); put(o.Bs, v.sp.Bs);
@@ -1492,6 +1503,34 @@ int oracle_trace_pixel(oracle_scene* S, uint64_t pass, uint64_t seed, uint32_t p
     if (n_light) *n_light = (uint32_t)L.size();
     if (I) { I[0] = Iv.x; I[1] = Iv.y; I[2] = Iv.z; }
     if (n_splats) *n_splats = ns;
+    return UBDPT_SUCCESS;
+}
+
+int oracle_connection_probe(oracle_scene* S, const oracle_vertex* eye, uint32_t n_eye, const oracle_vertex* light,
+                            uint32_t n_light, ubdpt_connection* out, double* s0) {
+    if (!S || !eye || !light || !out || n_eye == 0 || n_light == 0) return UBDPT_INVALID_ARG;
+    Tracer tr(*S, nullptr);
+    std::vector<PathVertex> E, L;
+    for (uint32_t t = 0; t < n_eye; t++) E.push_back(vertex_from(eye[t]));
+    for (uint32_t k = 0; k < n_light; k++) L.push_back(vertex_from(light[k]));
+    for (uint32_t s = 1; s <= n_light; s++)
+        for (uint32_t t = 1; t <= n_eye; t++) {
+            ubdpt_connection& o = out[(size_t)(s - 1) * n_eye + (t - 1)];
+            std::memset(&o, 0, sizeof(o));
+            dvec3 c{0, 0, 0};
+            if (!tr.connectionFactor(L, E, s, t, c)) continue;
+            o.connected = 1;
+            o.c[0] = c.x; o.c[1] = c.y; o.c[2] = c.z;
+            o.w = tr.weight(L, E, s, t);
+        }
+    if (s0) {
+        for (uint32_t k = 0; k < 3 * n_eye; k++) s0[k] = 0;
+        for (uint32_t t = 1; t < n_eye; t++) {
+            std::vector<PathVertex> sub(E.begin(), E.begin() + t);
+            dvec3 v = tr.s0sample(sub, E[t]);
+            s0[3 * t] = v.x; s0[3 * t + 1] = v.y; s0[3 * t + 2] = v.z;
+        }
+    }
     return UBDPT_SUCCESS;
 }
 

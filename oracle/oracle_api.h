@@ -40,17 +40,8 @@ typedef struct oracle_counters {
     uint64_t nodes_visited_closest;
 } oracle_counters;
 
-/* One stored path vertex, world space (UPathVertex, uengine/ubdptrenderer.h:9-24). */
-typedef struct oracle_vertex {
-    double  pos[3], Ng[3], Ns[3], Ts[3], Bs[3];
-    double  tex_u, tex_v;
-    double  a[3];
-    double  p_light_A, p_eye_A;
-    int32_t object;     /* -1 for the lens vertex */
-    int32_t lobe;       /* UBDPT_LOBE_* */
-    int32_t specular;
-    int32_t reserved;
-} oracle_vertex;
+/* One stored path vertex, world space (UPathVertex, uengine/ubdptrenderer.h:9-24): the layout of the backend's probe. */
+typedef ubdpt_path_vertex oracle_vertex;
 
 int  oracle_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* params,
                    uint32_t max_path_vertices, oracle_scene** out);
@@ -72,6 +63,11 @@ int  oracle_render_passes(oracle_scene* s, uint64_t first_pass, uint32_t n_passe
 int  oracle_trace_pixel(oracle_scene* s, uint64_t pass, uint64_t seed, uint32_t px, uint32_t py,
                         oracle_vertex* eye, uint32_t* n_eye, oracle_vertex* light, uint32_t* n_light,
                         double I[3], double* splats, uint32_t max_splats, uint32_t* n_splats);
+
+/* connectionFactor / weight / s0sample (uengine/ubdptrenderer.cpp:596-844, :156-222) on one pair of subpaths given as
+ * vertex arrays; same outputs as ubdpt_connection_probe (include/ubdpt.h). */
+int  oracle_connection_probe(oracle_scene* s, const oracle_vertex* eye, uint32_t n_eye, const oracle_vertex* light,
+                             uint32_t n_light, ubdpt_connection* out, double* s0);
 
 int  oracle_intersect_batch(oracle_scene* s, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);
 int  oracle_visibility_batch(oracle_scene* s, const ubdpt_segment* segs, size_t n, uint8_t* visible);

@@ -50,6 +50,7 @@ def lib():
         l.oracle_trace_pixel.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_uint32),
                                          vp, C.POINTER(C.c_uint32), vp, vp, C.c_uint32, C.POINTER(C.c_uint32)]
         l.oracle_intersect_batch.argtypes = [vp, vp, C.c_size_t, vp]
+        l.oracle_connection_probe.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
         l.oracle_visibility_batch.argtypes = [vp, vp, C.c_size_t, vp]
         l.oracle_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
         l.oracle_get_camera_info.argtypes = [vp, vp, vp, vp]
@@ -111,6 +112,16 @@ class Oracle:
                                          C.byref(ns))
         assert st == 0
         return eye[:ne.value], light[:nl.value], I, splats[:min(ns.value, max_splats)]
+
+    def connection_probe(self, eye, light):
+        """connectionFactor / weight for every (s, t) and s0sample for every eye prefix of one pair of subpaths
+        (arrays of VERTEX_DTYPE): (connections [n_light, n_eye] of capi.CONNECTION_DTYPE, s0 [n_eye, 3])."""
+        eye = np.ascontiguousarray(eye, VERTEX_DTYPE); light = np.ascontiguousarray(light, VERTEX_DTYPE)
+        out = np.zeros((light.shape[0], eye.shape[0]), capi.CONNECTION_DTYPE)
+        s0 = np.zeros((eye.shape[0], 3))
+        assert self.lib.oracle_connection_probe(self.handle, eye.ctypes.data, eye.shape[0], light.ctypes.data,
+                                                light.shape[0], out.ctypes.data, s0.ctypes.data) == 0
+        return out, s0
 
     def intersect_batch(self, rays):
         rays = np.ascontiguousarray(rays, capi.RAY_DTYPE)

@@ -95,7 +95,7 @@ def test_backend_reproduces_scene_fixture(name, accel):
     # same uniforms on both sides; a handful of paths branch differently where the device's sin / cos
     # differ from glibc's in the last bit, so a few pixels may differ and the counters by a few units
     bad = np.abs(img - ref) > 1e-9 * (np.abs(ref) + 1e-3)
-    assert bad.any(axis=2).mean() <= 0.02
+    assert bad.any(axis=2).mean() <= 0.002  # observed 0; four pixels of a 48 x 48 image may branch on a last-bit sin / cos difference
     assert abs(img.mean() - ref.mean()) / ref.mean() < 5e-3
     got = np.array([st[k] for k in ("closest_hit_rays", "shadow_rays", "eye_vertices", "light_vertices", "connections", "splats")],
                    np.float64)

@@ -163,11 +163,21 @@ def test_bsdf_parity(oracle_mod):
     ctx.close()
 
 
+# Largest fraction of pixels that may deviate from the oracle by more than 1e-9 relative in a path-by-path
+# comparison. Observed over every such test of this suite: 0.000 % (the device's sin / cos differ from glibc's in
+# the last bit for a few arguments, which can send a path another way once in some 10^5 samples). The allowance is
+# four pixels of a 48 x 48 image.
+BAD_PIXELS_MAX = 0.002
+OBSERVED = []
+
+
 def image_agreement(got, ref, passes):
     """Fraction of pixels whose per-pass mean differs by more than 1e-9 (relative to max(1e-3, value))."""
     g = got / passes; r = ref / passes
     err = np.abs(g - r) / np.maximum(np.abs(r), 1e-3)
     bad = np.any(err > 1e-9, axis=2)
+    OBSERVED.append(float(bad.mean()))
+    print(f"pixels off by > 1e-9: {bad.mean() * 100:.4f} % (largest so far {max(OBSERVED) * 100:.4f} %)")
     return float(bad.mean()), rel_mse(g, r)
 
 
@@ -175,8 +185,8 @@ def image_agreement(got, ref, passes):
 @pytest.mark.parametrize("pipeline", [0, 1])
 @pytest.mark.parametrize("name,passes", [("C1", 4), ("C2", 4), ("tiny", 3), ("mesh6k", 2)])
 def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipeline):
-    """Same seed => same paths. Tolerance: at most 2 % of the pixels may deviate by more than 1e-9
-    relative (paths that branch differently after a last-bit sin/cos difference, plus the pixels their
+    """Same seed => same paths. Tolerance: at most BAD_PIXELS_MAX (0.2 %) of the pixels may deviate by more than
+    1e-9 relative (paths that branch differently after a last-bit sin/cos difference, plus the pixels their
     splats land on), relMSE of the whole image <= 2e-3, channel means within 0.5 %."""
     w = h = 48
     scene, ctx, orc = make_pair(oracle_mod, name, w=w, h=h, accel=accel, stats=1, pipeline=pipeline)
@@ -187,7 +197,7 @@ def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipe
     assert np.isfinite(got).all() == np.isfinite(ref).all()
     fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
     bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
-    assert bad <= 0.02, f"{bad:.4f} of pixels deviate"
+    assert bad <= BAD_PIXELS_MAX, f"{bad:.4f} of pixels deviate"
     assert rm <= 2e-3, rm
     mg, mr = got[fin].mean(0), ref[fin].mean(0)
     assert np.all(np.abs(mg - mr) <= 5e-3 * np.abs(mr) + 1e-12)
@@ -229,7 +239,7 @@ def test_image_parity_across_scene_sizes_that_change_the_memory_placement(oracle
     ref, cn = orc.render_passes(0, passes, SEED, num_threads=4, counters=True)
     fin = np.isfinite(ref).all(axis=2) & np.isfinite(got).all(axis=2)
     bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
-    assert bad <= 0.02 and rm <= 2e-3, (bad, rm)
+    assert bad <= BAD_PIXELS_MAX and rm <= 2e-3, (bad, rm)
     for k in ("eye_vertices", "light_vertices"):
         assert abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2, (k, s[k], cn[k])
     rh = orc.intersect_batch(rays)
@@ -267,7 +277,7 @@ def test_image_parity_for_other_render_parameters(oracle_mod, case, pipeline):
     assert np.array_equal(np.isfinite(ref), np.isfinite(got))
     bad, rm = image_agreement(np.where(fin[..., None], got, 0), np.where(fin[..., None], ref, 0), passes)
     if w * h >= 400:
-        assert bad <= 0.02 and rm <= 2e-3, (bad, rm)
+        assert bad <= BAD_PIXELS_MAX and rm <= 2e-3, (bad, rm)
     else:  # a handful of pixels: every one of them has to agree
         assert bad == 0.0, (got, ref)
     for k in ("eye_vertices", "light_vertices", "connections", "splats"):
@@ -466,7 +476,7 @@ def test_path_cap_matches_oracle(oracle_mod):
     got = ctx.read_sum()
     ref, cn = orc.render_passes(0, 4, SEED, counters=True)
     bad, rm = image_agreement(got, ref, 4)
-    assert bad <= 0.02 and rm <= 2e-3
+    assert bad <= BAD_PIXELS_MAX and rm <= 2e-3
     s = ctx.stats()
     assert cn["capped_subpaths"] > 0
     assert abs(s["capped_subpaths"] - cn["capped_subpaths"]) <= 0.01 * cn["capped_subpaths"] + 2
@@ -609,6 +619,59 @@ def test_large_mesh_emitter_is_sampled_like_the_reference_walk(oracle_mod):
     ref, cn = oracle_mod.Oracle(scene, params, 32).render_passes(0, passes, SEED, num_threads=8, counters=True)
     bad, rm = image_agreement(got, ref, passes)
     print(f"mesh emitter: {bad * 100:.3f} % of pixels off by > 1e-9")
-    assert bad <= 0.005 and rm <= 2e-3, (bad, rm)
+    assert bad <= BAD_PIXELS_MAX and rm <= 2e-3, (bad, rm)
     for k in ("eye_vertices", "light_vertices", "connections", "splats"):
         assert abs(s[k] - cn[k]) <= 2e-3 * cn[k] + 2, (k, s[k], cn[k])
+
+
+def _probe_compare(ctx, orc, eye, light, what):
+    got, got_s0 = ctx.connection_probe(eye, light)
+    ref, ref_s0 = orc.connection_probe(eye, light)
+    assert np.array_equal(got["connected"], ref["connected"]), what
+    m = ref["connected"] == 1
+    worst = 0.0
+    if m.any():
+        for f in ("c", "w"):
+            g, r = got[f][m], ref[f][m]
+            assert np.isfinite(r).all() == np.isfinite(g).all(), (what, f)
+            fin = np.isfinite(r)
+            rel = np.abs(g[fin] - r[fin]) / np.maximum(np.abs(r[fin]), 1e-300)
+            worst = max(worst, float(rel.max()) if rel.size else 0.0)
+    fin = np.isfinite(ref_s0)
+    assert np.array_equal(fin, np.isfinite(got_s0)), what
+    rel = np.abs(got_s0[fin] - ref_s0[fin]) / np.maximum(np.abs(ref_s0[fin]), 1e-300)
+    rel = rel[np.abs(ref_s0[fin]) > 0]
+    assert np.array_equal(got_s0[fin] == 0, ref_s0[fin] == 0), what
+    worst = max(worst, float(rel.max()) if rel.size else 0.0)
+    return int(m.sum()), int((ref_s0 != 0).any(axis=1).sum()), worst
+
+
+def test_connection_factor_mis_weight_and_s0_sample_probes(oracle_mod):
+    """connectionFactor, weight and s0sample (ubdptrenderer.cpp:156-222, 596-844) of the device code, probed directly
+    on subpaths handed in as vertex arrays: the six subpath pairs frozen in tests/golden/paths_C2.npz and the pairs the
+    oracle traces for a few hundred pixels of the C2 and the tiny scene (specular chains, s = 1, t = 1, emitter hits).
+    The same (s, t) must connect, and c, w and the s = 0 value agree to 1e-12 relative (the device evaluates the
+    Lambertian case in a simplified but algebraically identical form)."""
+    from util import load_golden
+    g = load_golden("paths_C2.npz")
+    scene, ctx, orc = make_pair(oracle_mod, "C2", w=64, h=64)
+    n_conn = n_s0 = 0
+    worst = 0.0
+    for k in range(6):
+        a, b, wv = _probe_compare(ctx, orc, g[f"p{k}_eye"], g[f"p{k}_light"], f"golden path {k}")
+        n_conn += a; n_s0 += b; worst = max(worst, wv)
+    ctx.close()
+    for name in ("C2", "tiny"):
+        scene, ctx, orc = make_pair(oracle_mod, name, w=64, h=64)
+        rng = np.random.default_rng(5)
+        for _ in range(150):
+            px, py, p = int(rng.integers(0, 64)), int(rng.integers(0, 64)), int(rng.integers(0, 8))
+            eye, light, I, splats = orc.trace_pixel(p, SEED, px, py)
+            if len(light) == 0 or len(eye) == 0:
+                continue
+            a, b, wv = _probe_compare(ctx, orc, eye, light, f"{name} pixel {px},{py} pass {p}")
+            n_conn += a; n_s0 += b; worst = max(worst, wv)
+        ctx.close()
+    print(f"connection probes: {n_conn} connected pairs, {n_s0} s=0 samples, worst relative deviation {worst:.2e}")
+    assert n_conn > 500 and n_s0 > 5
+    assert worst <= 1e-12

@@ -172,7 +172,7 @@ def test_backend_renders_loaded_scene_like_oracle(tmp_path):
         ctx.render_passes(0, 4, 0x5EED)
         got = ctx.read_sum()
     bad = np.abs(got - ref) > 1e-9 * (np.abs(ref) + 1e-3)
-    assert bad.any(axis=2).mean() <= 0.02 and abs(got.mean() - ref.mean()) / ref.mean() < 5e-3
+    assert bad.any(axis=2).mean() <= 0.005 and abs(got.mean() - ref.mean()) / ref.mean() < 5e-3
     # and through the engine, which takes the loaded scene as its scene source
     with hostapi.Engine(xs) as eng:
         assert eng.new_rendering(params) == hostapi.USUCCESS and eng.render_passes(4) == hostapi.USUCCESS
