@@ -176,19 +176,31 @@ V3 normalized(V3 a) {
     return l > 0 ? mul(a, 1.0 / l) : V3{0, 0, 0};
 }
 
-bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::string& error) {
+// Reads a Wavefront OBJ file into triangle corners appended to `out`; `part_faces` receives the face count of
+// each model the file yields, in order. The reference hands every aiMesh of the imported file to its own
+// Object/Emitter (uapp/scene.cpp:181-190, :284-327); the importer makes one mesh per `o` object and material
+// and, with aiProcess_OptimizeMeshes, joins the `g` groups of one object that share a material. The importer
+// itself is a third-party library that is not part of the reference tree, so this division (and the order of
+// the parts: first appearance in the file) restates its documented behaviour and is not pinned by a fixture.
+bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::vector<size_t>& part_faces,
+             std::string& error) {
     std::ifstream in(path);
     if (!in.is_open()) { error = "cannot open mesh file " + path; return false; }
     std::vector<V3> pos, nrm;
     std::vector<std::pair<double, double>> uv;
     struct Corner { int p, t, n; };
-    std::vector<Corner> corners;  // 3 per triangle
+    std::vector<std::vector<Corner>> parts;  // per model: 3 corners per triangle
+    std::map<std::pair<int, std::string>, size_t> part_of;
+    int object_index = 0;
+    std::string material;
     std::string line;
     while (std::getline(in, line)) {
         std::istringstream ls(line);
         std::string kw;
         ls >> kw;
-        if (kw == "v") { V3 p{}; ls >> p.x >> p.y >> p.z; p.z = -p.z; pos.push_back(p); }         // left-handed: z negated
+        if (kw == "o") object_index++;
+        else if (kw == "usemtl") { material.clear(); ls >> material; }
+        else if (kw == "v") { V3 p{}; ls >> p.x >> p.y >> p.z; p.z = -p.z; pos.push_back(p); }         // left-handed: z negated
         else if (kw == "vn") { V3 n{}; ls >> n.x >> n.y >> n.z; n.z = -n.z; nrm.push_back(n); }
         else if (kw == "vt") { double u = 0, v = 0; ls >> u >> v; uv.emplace_back(u, v); }
         else if (kw == "f") {
@@ -210,60 +222,70 @@ bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::
                 if (c.n < 0) c.n = (int)nrm.size() + c.n + 1;
                 poly.push_back(c);
             }
+            if (poly.size() < 3) continue;  // points and lines: aiProcess_SortByPType keeps them out of triangle meshes
+            auto key = std::make_pair(object_index, material);
+            auto it = part_of.find(key);
+            if (it == part_of.end()) { it = part_of.emplace(key, parts.size()).first; parts.emplace_back(); }
+            std::vector<Corner>& corners = parts[it->second];
             for (size_t k = 1; k + 1 < poly.size(); k++) {  // aiProcess_Triangulate: fan
                 corners.push_back(poly[0]); corners.push_back(poly[k]); corners.push_back(poly[k + 1]);
             }
         }
     }
-    if (corners.empty()) { error = "mesh has no faces: " + path; return false; }
-    for (const Corner& c : corners)
-        if (c.p < 1 || c.p > (int)pos.size() || c.t > (int)uv.size() || c.n > (int)nrm.size()) {
-            error = "face index out of range in " + path;
-            return false;
-        }
-    // aiProcess_GenSmoothNormals when the file has none: area-weighted face normals summed per position
-    std::vector<V3> smooth;
-    bool need_normals = false;
-    for (const Corner& c : corners) need_normals |= (c.n == 0);
-    if (need_normals) {
-        smooth.assign(pos.size(), V3{0, 0, 0});
-        for (size_t f = 0; f < corners.size(); f += 3) {
-            V3 p0 = pos[corners[f].p - 1], p1 = pos[corners[f + 1].p - 1], p2 = pos[corners[f + 2].p - 1];
-            V3 fn = cross(sub(p1, p0), sub(p2, p0));
-            for (int k = 0; k < 3; k++) smooth[corners[f + k].p - 1] = add(smooth[corners[f + k].p - 1], fn);
-        }
-    }
-    out.reserve(out.size() + corners.size());
-    for (size_t f = 0; f < corners.size(); f += 3) {
-        V3 p[3], n[3];
-        double u[3], v[3];
-        for (int k = 0; k < 3; k++) {
-            const Corner& c = corners[f + k];
-            p[k] = pos[c.p - 1];
-            n[k] = normalized(c.n ? nrm[c.n - 1] : smooth[c.p - 1]);
-            // aiProcess_GenUVCoords without a mapping leaves missing coordinates at 0
-            u[k] = c.t ? uv[c.t - 1].first : 0.0;
-            v[k] = c.t ? uv[c.t - 1].second : 0.0;
-        }
-        // aiProcess_CalcTangentSpace, per face: tangent along increasing u
-        V3 e1 = sub(p[1], p[0]), e2 = sub(p[2], p[0]);
-        double sx = u[1] - u[0], sy = v[1] - v[0], tx = u[2] - u[0], ty = v[2] - v[0];
-        double dir = (tx * sy - ty * sx) < 0.0 ? -1.0 : 1.0;
-        if (sx * ty == sy * tx) { sx = 0.0; sy = 1.0; tx = 1.0; ty = 0.0; }
-        V3 tangent = mul(sub(mul(e2, sy), mul(e1, ty)), dir);
-        for (int k = 0; k < 3; k++) {
-            V3 t = normalized(sub(tangent, mul(n[k], dot(tangent, n[k]))));  // Gram-Schmidt against the vertex normal
-            if (t.x == 0 && t.y == 0 && t.z == 0) {  // degenerate uv: any vector orthogonal to the normal
-                V3 h = std::fabs(n[k].x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
-                t = normalized(cross(h, n[k]));
+    if (parts.empty()) { error = "mesh has no faces: " + path; return false; }
+    for (const std::vector<Corner>& corners : parts)
+        for (const Corner& c : corners)
+            if (c.p < 1 || c.p > (int)pos.size() || c.t > (int)uv.size() || c.n > (int)nrm.size()) {
+                error = "face index out of range in " + path;
+                return false;
             }
-            ubdpt_mesh_vertex mv;
-            mv.pos[0] = (float)p[k].x; mv.pos[1] = (float)p[k].y; mv.pos[2] = (float)p[k].z;
-            mv.normal[0] = (float)n[k].x; mv.normal[1] = (float)n[k].y; mv.normal[2] = (float)n[k].z;
-            mv.tangent[0] = (float)t.x; mv.tangent[1] = (float)t.y; mv.tangent[2] = (float)t.z;
-            mv.uv[0] = (float)u[k]; mv.uv[1] = (float)v[k];
-            out.push_back(mv);
+    for (const std::vector<Corner>& corners : parts) {
+        // aiProcess_GenSmoothNormals when the file has none: area-weighted face normals summed per position,
+        // within one model (the importer smooths each mesh on its own)
+        std::vector<V3> smooth;
+        bool need_normals = false;
+        for (const Corner& c : corners) need_normals |= (c.n == 0);
+        if (need_normals) {
+            smooth.assign(pos.size(), V3{0, 0, 0});
+            for (size_t f = 0; f < corners.size(); f += 3) {
+                V3 p0 = pos[corners[f].p - 1], p1 = pos[corners[f + 1].p - 1], p2 = pos[corners[f + 2].p - 1];
+                V3 fn = cross(sub(p1, p0), sub(p2, p0));
+                for (int k = 0; k < 3; k++) smooth[corners[f + k].p - 1] = add(smooth[corners[f + k].p - 1], fn);
+            }
         }
+        out.reserve(out.size() + corners.size());
+        for (size_t f = 0; f < corners.size(); f += 3) {
+            V3 p[3], n[3];
+            double u[3], v[3];
+            for (int k = 0; k < 3; k++) {
+                const Corner& c = corners[f + k];
+                p[k] = pos[c.p - 1];
+                n[k] = normalized(c.n ? nrm[c.n - 1] : smooth[c.p - 1]);
+                // aiProcess_GenUVCoords without a mapping leaves missing coordinates at 0
+                u[k] = c.t ? uv[c.t - 1].first : 0.0;
+                v[k] = c.t ? uv[c.t - 1].second : 0.0;
+            }
+            // aiProcess_CalcTangentSpace, per face: tangent along increasing u
+            V3 e1 = sub(p[1], p[0]), e2 = sub(p[2], p[0]);
+            double sx = u[1] - u[0], sy = v[1] - v[0], tx = u[2] - u[0], ty = v[2] - v[0];
+            double dir = (tx * sy - ty * sx) < 0.0 ? -1.0 : 1.0;
+            if (sx * ty == sy * tx) { sx = 0.0; sy = 1.0; tx = 1.0; ty = 0.0; }
+            V3 tangent = mul(sub(mul(e2, sy), mul(e1, ty)), dir);
+            for (int k = 0; k < 3; k++) {
+                V3 t = normalized(sub(tangent, mul(n[k], dot(tangent, n[k]))));  // Gram-Schmidt against the vertex normal
+                if (t.x == 0 && t.y == 0 && t.z == 0) {  // degenerate uv: any vector orthogonal to the normal
+                    V3 h = std::fabs(n[k].x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
+                    t = normalized(cross(h, n[k]));
+                }
+                ubdpt_mesh_vertex mv;
+                mv.pos[0] = (float)p[k].x; mv.pos[1] = (float)p[k].y; mv.pos[2] = (float)p[k].z;
+                mv.normal[0] = (float)n[k].x; mv.normal[1] = (float)n[k].y; mv.normal[2] = (float)n[k].z;
+                mv.tangent[0] = (float)t.x; mv.tangent[1] = (float)t.y; mv.tangent[2] = (float)t.z;
+                mv.uv[0] = (float)u[k]; mv.uv[1] = (float)v[k];
+                out.push_back(mv);
+            }
+        }
+        part_faces.push_back(corners.size() / 3);
     }
     return true;
 }
@@ -379,16 +401,20 @@ struct SceneBuilderAccess {
             }
             if (const XmlNode* x = xo.first("scale")) { scl[0] = child(x, "x"); scl[1] = child(x, "y"); scl[2] = child(x, "z"); }
             M4 T = scale(rotate(translate(identity(), trans), angle, rot), scl);
-            size_t first_vertex = s.m_vertices.size();
-            if (!xf || !loadObj(joinPath(base_dir, xf->text), s.m_vertices, error)) {
+            size_t first_face = s.m_vertices.size() / 3;
+            std::vector<size_t> part_faces;
+            if (!xf || !loadObj(joinPath(base_dir, xf->text), s.m_vertices, part_faces, error)) {
                 if (error.empty()) error = "Failed to load scene.";
                 return false;
             }
             proto.kind = UBDPT_MODEL_MESH;
             std::memcpy(proto.W, T.c, sizeof(proto.W));
-            proto.first_face = first_vertex / 3;
-            proto.num_faces = (s.m_vertices.size() - first_vertex) / 3;
-            s.m_objects.push_back(proto);
+            for (size_t faces : part_faces) {  // one object (or emitter) per model of the file (:184-190)
+                proto.first_face = first_face;
+                proto.num_faces = faces;
+                s.m_objects.push_back(proto);
+                first_face += faces;
+            }
         }
         // any other type: the reference adds nothing (:119-191)
         return true;

@@ -147,6 +147,54 @@ def test_loaded_scene_renders_like_python_twin(tmp_path):
     assert a.sum() > 0 and np.allclose(a, b, rtol=1e-9, atol=1e-12)
 
 
+GROUPED_OBJ = """o first
+v 0 0 0
+v 1 0 0
+v 1 1 0
+v 0 1 0
+vn 0 0 -1
+vt 0 0
+vt 1 0
+vt 1 1
+vt 0 1
+usemtl red
+g front
+f 1/1/1 2/2/1 3/3/1
+usemtl blue
+f 1/1/1 3/3/1 4/4/1
+usemtl red
+g back
+f 2/1/1 3/2/1 4/3/1
+p 1
+o second
+usemtl red
+f 1/1/1 2/2/1 4/4/1 3/3/1
+"""
+
+
+def test_obj_file_yields_one_object_per_model(tmp_path):
+    """Every model of a mesh file becomes its own object with the element's material, transform and emission
+    (uapp/scene.cpp:181-190): one per `o` object and material, groups of one object joined per material.
+    The division restates the import library's behaviour (the library is not in the reference tree): not pinned
+    by a reference fixture."""
+    write_files(tmp_path)
+    (tmp_path / "grouped.obj").write_text(GROUPED_OBJ)
+    (tmp_path / "grouped.xml").write_text(XML.replace("light.obj", "grouped.obj"))
+    xs = hostapi.XmlScene(str(tmp_path / "grouped.xml"), str(tmp_path))
+    objs = [xs.objects[i] for i in range(xs.n_objects)]
+    meshes = [o for o in objs if o.kind == capi.MODEL_MESH]
+    # floor, then first/red (2 faces: both groups), first/blue (1), second/red (a quad: 2), then the glossy floor
+    assert [(o.first_face, o.num_faces) for o in meshes] == [(0, 2), (2, 2), (4, 1), (5, 2), (7, 2)]
+    assert [o.is_emitter for o in meshes] == [0, 1, 1, 1, 0]
+    assert all(list(o.power) == [20, 19, 18] and list(o.W) == list(meshes[1].W) for o in meshes[1:4])
+    v = xs.vertices()
+    # the red model of `first` holds the faces of both groups in file order
+    assert np.array_equal(v["pos"][6:12, :2], np.array([[0, 0], [1, 0], [1, 1], [1, 0], [1, 1], [0, 1]], np.float32))
+    params = scenes.make_params(16, 12)
+    img = oracle_py.Oracle(xs, params).render_passes(0, 2, 3, num_threads=2)
+    assert np.isfinite(img).all() and img.sum() > 0
+
+
 def test_loader_errors(tmp_path):
     write_files(tmp_path)
     with pytest.raises(RuntimeError, match="Failed to open scene file"):
