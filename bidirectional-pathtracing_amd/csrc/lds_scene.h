@@ -26,8 +26,8 @@ DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
     return lds;
 }
 
-// In LDS a node occupies 144 bytes: with the 128-byte stride of the HBM layout the lanes of a wave
-// that read the same field of different nodes would all hit the same few banks.
+// In LDS a node is followed by 16 bytes of padding: with the power-of-two stride of the HBM layout the lanes of
+// a wave that read the same field of different nodes would all hit the same few banks.
 struct __attribute__((aligned(16))) LdsNode {
     BvhNode n;
     uint32_t pad[4];
@@ -37,7 +37,7 @@ struct __attribute__((aligned(16))) LdsNode {
 DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
     static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
     constexpr uint32_t kNodeWords = sizeof(BvhNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
-    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : S.num_prims;  // nodes of the binary tree the four-wide one is carved from
+    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : S.num_prims;  // slots of the node array: one per node of the binary tree the wide one is carved from
     const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
     uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
     for (uint32_t w = threadIdx.x; w < n_nodes * kNodeWords; w += kBlock)

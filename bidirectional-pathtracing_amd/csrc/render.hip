@@ -1021,3 +1021,11 @@ hipError_t launchIntersectBatchNoAlloc(const DScene& S, const ubdpt_ray* rays, s
 }
 
 }  // namespace ub
+
+#ifdef UBDPT_WAVE_TIMES
+extern "C" void ubdpt_debug_wave_times(unsigned long long* out) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ub::g_wave_times), sizeof(unsigned long long) * 16 * 12);
+    (void)hipMemcpyFromSymbol(out + 16 * 12, HIP_SYMBOL(ub::g_wave_phase), sizeof(unsigned long long) * 8);
+}
+#endif

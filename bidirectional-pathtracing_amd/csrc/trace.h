@@ -1,8 +1,8 @@
 // trace.h — ray / scene intersection on the device.
 //
 // Replaces UScene::intersectionPoint and UScene::visibility (uengine/uscene.cpp:21-66), which scan
-// every object and every face. Here a ray walks a world-space LBVH (128-byte four-child nodes) with a
-// per-lane stack whose first kLdsStack entries live in LDS ([entry][lane], bank = lane, conflict
+// every object and every face. Here a ray walks a world-space LBVH (wide nodes with quantised child boxes,
+// scene.h) with a per-lane stack whose first kLdsStack entries live in LDS ([entry][lane], bank = lane, conflict
 // free) and whose rare overflow goes to a per-lane slice of HBM. Boxes are tested in fp32 with a
 // conservative slab test; candidate primitives are tested
 // exactly as the reference tests them: in object-local space, in fp64, in the reference's operation
@@ -202,8 +202,8 @@ struct Stack {
 
 constexpr int32_t kTraversalDone = kEmptyChild;
 
-// One traversal step from an internal node: tests both children, returns the next node to visit
-// (near child first, far child pushed) or pops / finishes when neither child is hit.
+// One traversal step from an internal node: tests the children, returns the nearest one that is hit and pushes
+// the others (farthest first), or pops / finishes when no child is hit.
 DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
     if (tb < ta) { float t = ta; ta = tb; tb = t; int32_t c = ca; ca = cb; cb = c; }
 }
@@ -214,22 +214,36 @@ DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st,
     if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
 
     const float inf = __builtin_inff();
-    float t0, t1, t2, t3;
-    int32_t c0 = nd.child[0], c1 = nd.child[1], c2 = nd.child[2], c3 = nd.child[3];
-    if (!(c0 != kEmptyChild && slabF(nd.lo[0], nd.hi[0], q, tmax, t0))) t0 = inf;
-    if (!(c1 != kEmptyChild && slabF(nd.lo[1], nd.hi[1], q, tmax, t1))) t1 = inf;
-    if (!(c2 != kEmptyChild && slabF(nd.lo[2], nd.hi[2], q, tmax, t2))) t2 = inf;
-    if (!(c3 != kEmptyChild && slabF(nd.lo[3], nd.hi[3], q, tmax, t3))) t3 = inf;
-    // entry distances are finite for a hit (the ray parameter interval is clipped to [.., tmax]); sort near
-    // to far with a five-comparator network, misses (inf) end up last
-    sortPair(t0, c0, t1, c1); sortPair(t2, c2, t3, c3);
-    sortPair(t0, c0, t2, c2); sortPair(t1, c1, t3, c3);
-    sortPair(t1, c1, t2, c2);
-    if (t3 < inf) st.push(c3);
-    if (t2 < inf) st.push(c2);
-    if (t1 < inf) st.push(c1);
+    float t[kNodeWidth];
+    int32_t c[kNodeWidth];
+    const float sx = nodeStep(nd.exps, 0), sy = nodeStep(nd.exps, 1), sz = nodeStep(nd.exps, 2);
+#pragma unroll
+    for (int k = 0; k < kNodeWidth; k++) {
+        c[k] = nd.child[k];
+        const int w = k >> 2, sh = 8 * (k & 3);
+        const float lo[3] = {nodeCoord(nd.origin[0], (nd.q[0][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[1][w] >> sh) & 0xffu, sy),
+                             nodeCoord(nd.origin[2], (nd.q[2][w] >> sh) & 0xffu, sz)};
+        const float hi[3] = {nodeCoord(nd.origin[0], (nd.q[3][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[4][w] >> sh) & 0xffu, sy),
+                             nodeCoord(nd.origin[2], (nd.q[5][w] >> sh) & 0xffu, sz)};
+        if (!(c[k] != kEmptyChild && slabF(lo, hi, q, tmax, t[k]))) t[k] = inf;
+    }
+    // entry distances are finite for a hit (the ray parameter interval is clipped to [.., tmax]); sort near to far
+    // with a comparator network (5 comparators for four, 19 for eight), misses (inf) end up last
+    if (kNodeWidth == 4) {
+        sortPair(t[0], c[0], t[1], c[1]); sortPair(t[2], c[2], t[3], c[3]);
+        sortPair(t[0], c[0], t[2], c[2]); sortPair(t[1], c[1], t[3], c[3]);
+        sortPair(t[1], c[1], t[2], c[2]);
+    } else {
+        constexpr int kNet[19][2] = {{0, 1}, {2, 3}, {4, 5}, {6, 7}, {0, 2}, {1, 3}, {4, 6}, {5, 7}, {1, 2}, {5, 6},
+                                     {0, 4}, {3, 7}, {1, 5}, {2, 6}, {1, 4}, {3, 6}, {2, 4}, {3, 5}, {3, 4}};
+#pragma unroll
+        for (int k = 0; k < 19; k++) sortPair(t[kNet[k][0] % kNodeWidth], c[kNet[k][0] % kNodeWidth], t[kNet[k][1] % kNodeWidth], c[kNet[k][1] % kNodeWidth]);
+    }
+#pragma unroll
+    for (int k = kNodeWidth - 1; k >= 1; k--)
+        if (t[k] < inf) st.push(c[k]);
     if (tc && (uint32_t)st.sp > tc->max_stack) tc->max_stack = (uint32_t)st.sp;
-    if (t0 < inf) return c0;
+    if (t[0] < inf) return c[0];
     return st.sp ? st.pop() : kTraversalDone;
 }
 DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,

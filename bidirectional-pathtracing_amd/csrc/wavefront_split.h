@@ -128,6 +128,19 @@ DEV bool feedLanes(WaveFeed& f, uint32_t* head, uint32_t total, uint32_t chunk, 
 // record. The closest hit (object -1: none) goes to the subpath's hit record.
 // (Generating the subpaths inside the first launch of this kernel instead of in k_wf_gen was measured: the generation
 // code costs the kernel a quarter of its occupancy, inlined or not, and the whole is slower: 411 against 418 Mpaths/s.)
+#ifdef UBDPT_WAVE_TIMES
+// measurement build: per-wave lifetime of k_wf_trace in ticks of the constant 100 MHz clock
+// per depth: [0] waves that got work, [1] sum of lifetimes, [2] sum of time after the queue was found empty,
+// [3] loop iterations, [4] iterations with a node step, [5] waves that found the queue empty at once,
+// [6] longest lifetime, [7] ticks spent waiting for queue claims, [8] launches, [9] rays, [10] iterations with primitive tests
+__device__ unsigned long long g_wave_times[16][12];
+// phases of the loop, summed over waves (ticks): [0] arrivals, [1] feeding, [2] node fetch wait, [3] node step arithmetic,
+// [4] primitive fetch wait, [5] primitive arithmetic
+__device__ unsigned long long g_wave_phase[8];
+#define WT_STAMP(k) { const unsigned long long n_ = wall_clock64(); wt_phase[k] += n_ - wt_last; wt_last = n_; }
+#else
+#define WT_STAMP(k)
+#endif
 template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
@@ -162,7 +175,17 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
     best.d = 0; best.u = 0; best.v = 0; best.object = -1; best.face = 0;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
+#ifdef UBDPT_WAVE_TIMES
+    const unsigned long long wt_start = wall_clock64();
+    unsigned long long wt_drained = 0, wt_iters = 0, wt_steps = 0, wt_claim = 0, wt_leaf = 0;
+    unsigned long long wt_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = wt_start;
+    if (gid == 0 && !STATS) { atomicAdd(&g_wave_times[depth][8], 1ULL); atomicAdd(&g_wave_times[depth][9], (unsigned long long)total); }
+#endif
     for (;;) {
+#ifdef UBDPT_WAVE_TIMES
+        wt_iters++;
+        if (feed.drained && !wt_drained) wt_drained = wall_clock64();
+#endif
         // (1) lanes whose request of the previous iteration has arrived
         if (state == ST_RAY) {
             best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
@@ -194,11 +217,20 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
             cnt_word = reinterpret_cast<const uint32_t*>(p + kCarryCountSlot)[0];
             state = ST_RAY;
         }
+        WT_STAMP(0)
         // (2) idle lanes take the next queue entries
         const unsigned long long idle_m = __ballot(state == ST_IDLE);
         const unsigned long long act_m = __ballot(state == ST_ACTIVE);
         if (!feed.drained && ((int)__popcll(idle_m) >= kRefillMin || act_m == 0)) {
-            if (feedLanes(feed, head, total, chunk, idle_m, state == ST_IDLE, idx)) {
+#ifdef UBDPT_WAVE_TIMES
+            const bool wt_c = feed.next == feed.end;
+            const unsigned long long wt_t0 = wt_c ? wall_clock64() : 0;
+#endif
+            const bool fed = feedLanes(feed, head, total, chunk, idle_m, state == ST_IDLE, idx);
+#ifdef UBDPT_WAVE_TIMES
+            if (wt_c) wt_claim += wall_clock64() - wt_t0;
+#endif
+            if (fed) {
                 if (depth == 0) {  // uniform
                     id = idx;
                     const double* p = A.carry + (uint64_t)id * kCarryDoubles;
@@ -212,19 +244,64 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
                 }
             }
         }
+        WT_STAMP(1)
         if (feed.drained && idle_m == ~0ULL) break;
         if (act_m == 0) continue;
+#ifdef UBDPT_WAVE_TIMES
+        wt_steps++;
+#endif
         // (3) one node step for every lane that stands at an inner node
+#ifdef UBDPT_WAVE_TIMES
+        BvhNode wt_nd;
+        if (state == ST_ACTIVE && node >= 0) wt_nd = loadNode(S, node);
+        __builtin_amdgcn_s_waitcnt(0);
+        WT_STAMP(2)
+        if (state == ST_ACTIVE && node >= 0) {
+            node = descendNode(wt_nd, rq, tmax, st, tc);
+            if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
+        }
+        WT_STAMP(3)
+#else
         if (state == ST_ACTIVE && node >= 0) {
             node = descend(S, node, rq, tmax, st, true, tc);
             if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
         }
+#endif
         // (4) primitive tests, once enough lanes hold a leaf or nothing else can move
         const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
         if (leaf_m != 0) {
             const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
             if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
                 leaf_wait = 0;
+#ifdef UBDPT_WAVE_TIMES
+                wt_leaf++;
+#endif
+#ifdef UBDPT_WAVE_TIMES
+                Prim wt_pr;
+                if (state == ST_ACTIVE && node < 0) wt_pr = S.prims[~node];
+                __builtin_amdgcn_s_waitcnt(0);
+                WT_STAMP(4)
+                const bool wt_on = state == ST_ACTIVE && node < 0;
+                if (wt_on) cacheObject(S, ray, (int32_t)wt_pr.object, c);
+                WT_STAMP(5)
+                double wt_d = 0, wt_u = 0, wt_v = 0;
+                bool wt_hit = false;
+                if (wt_on) {
+                    if (wt_pr.face == kSphereFace) wt_hit = intersectUnitSphere(c.l.o, c.l.d, wt_d);
+                    else wt_hit = intersectTriangle(c.l.o, c.l.d, loadP(wt_pr.p), loadP(wt_pr.p + 3), loadP(wt_pr.p + 6), wt_d, wt_u, wt_v);
+                }
+                WT_STAMP(6)
+                if (wt_on) {
+                    if (wt_hit && lexLess(wt_d, (int32_t)wt_pr.object, wt_pr.face, best) &&
+                        (wt_pr.face == kSphereFace || meshGate(S, (int32_t)wt_pr.object, c))) {
+                        best.d = wt_d; best.u = wt_u; best.v = wt_v; best.object = (int32_t)wt_pr.object; best.face = wt_pr.face;
+                    }
+                    tmax = floatUp(best.d);
+                    node = st.sp ? st.pop() : kTraversalDone;
+                    if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
+                }
+                WT_STAMP(7)
+#else
                 if (state == ST_ACTIVE && node < 0) {
                     if (STATS) { tc->prims++; countWaveStep(tc->wave_prims); }
                     testPrimClosest(S, ray, S.prims[~node], c, best);
@@ -232,9 +309,28 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
                     node = st.sp ? st.pop() : kTraversalDone;
                     if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
                 }
+#endif
             }
         }
     }
+#ifdef UBDPT_WAVE_TIMES
+    if ((threadIdx.x & 63) == 0 && !STATS) {
+        const unsigned long long now = wall_clock64();
+        unsigned long long* g = g_wave_times[depth];
+        if (wt_iters > 2) {
+            atomicAdd(&g[0], 1ULL);
+            atomicAdd(&g[1], now - wt_start);
+            atomicAdd(&g[2], now - (wt_drained ? wt_drained : now));
+            atomicAdd(&g[3], wt_iters);
+            atomicAdd(&g[4], wt_steps);
+            atomicMax(&g[6], now - wt_start);
+            atomicAdd(&g[7], wt_claim);
+            atomicAdd(&g[10], wt_leaf);
+            for (int k = 0; k < 8; k++) atomicAdd(&g_wave_phase[k], wt_phase[k]);
+        } else
+            atomicAdd(&g[5], 1ULL);
+    }
+#endif
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
