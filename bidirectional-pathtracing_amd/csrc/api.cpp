@@ -343,7 +343,7 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
             for (uint64_t f = 0; f < o.num_faces; f++) {
                 Prim p;
                 memcpy(p.p, &face_pos[9 * (o.first_face + f)], sizeof(float) * 9);
-                p.object = i; p.face = (uint32_t)f; p.pad = 0;
+                p.object = i; p.face = (uint32_t)f; for (uint32_t& x : p.pad) x = 0;
                 prims.push_back(p);
             }
         } else {
@@ -690,9 +690,14 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.wf_hit = B.d_wf_hit; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
         A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag; A.ray_pairs = B.d_ray_pairs;
         double units = (double)A.E.n;
-        // persistent grids: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers
-        // grid-stride kernels; 512 .. 16384 workgroups measured within 2 % of each other
+        // grid-stride kernels: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers;
+        // 512 .. 16384 workgroups measured within 2 % of each other
         unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
+        // the two persistent ray tracing kernels: what the GPU holds at once (256 CUs x 4 workgroups of 4 waves). A
+        // larger grid only queues workgroups that find the ray queue empty; measured on the 2 M-triangle scene:
+        // 2048 workgroups 234, 1024: 239, 768: 231, 512: 225 Mpaths/s. UBDPT_TRACE_BLOCKS overrides it for measurements.
+        static const unsigned tblocks_env = [] { const char* e = getenv("UBDPT_TRACE_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
+        const unsigned tblocks = std::min(tblocks_env ? tblocks_env : 1024u, pblocks);
         uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
         // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, setup, rays, compact, eval (default)
         //           1 = per-path subpath kernels + per-path connection loop (the reference's loop structure, kept as a cross-check)
@@ -715,7 +720,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.ovf_stride = pstride;
             run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
             for (uint32_t d = 0; d < D; d++) {
-                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, pblocks, stats, sm); });
+                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, tblocks, stats, sm); });
                 run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
             }
             run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
@@ -726,7 +731,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
             A.ovf_stride = pstride;
             run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
-            run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, pblocks, stats, sm); });
+            run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, tblocks, stats, sm); });
             run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
             run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
         } else {

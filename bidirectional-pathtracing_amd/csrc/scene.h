@@ -1,7 +1,7 @@
 // scene.h — flattened scene as it lives in HBM, shared by host and device code.
 //
 // Layout decisions (MI355X): everything a ray touches on the way down the tree is 16-byte aligned
-// and sized in whole 16-byte lanes (64-byte nodes, 48-byte primitives) so a lane fetches a node or a
+// and sized in whole 16-byte lanes (64-byte nodes, 64-byte primitives) so a lane fetches a node or a
 // primitive with dwordx4 loads; per-face shading attributes are kept apart from positions because
 // only the one winning face of a ray needs them.
 #pragma once
@@ -72,16 +72,20 @@ __host__ __device__ inline float nodeCoord(float origin, uint32_t q, float step)
     return origin + m;
 }
 
-// 48-byte primitive in tree (Morton) order: object-LOCAL float positions exactly as the mesh holds
+// Primitive in tree (Morton) order, one 64-byte line each (48-byte records straddle two lines half of the time;
+// measured: 1 % apart): object-LOCAL float positions exactly as the mesh holds
 // them (uapp/mesh.cpp:20-21), the owning object and the face index inside that object's mesh.
 // Spheres are one primitive with face == kSphereFace.
+#ifndef UBDPT_PRIM_BYTES
+#define UBDPT_PRIM_BYTES 64
+#endif
 struct __attribute__((aligned(16))) Prim {
     float p[9];
     uint32_t object;
     uint32_t face;
-    uint32_t pad;
+    uint32_t pad[(UBDPT_PRIM_BYTES - 44) / 4];
 };
-static_assert(sizeof(Prim) == 48, "Prim must be 48 bytes");
+static_assert(sizeof(Prim) == UBDPT_PRIM_BYTES && (UBDPT_PRIM_BYTES == 48 || UBDPT_PRIM_BYTES == 64), "Prim is 48 or 64 bytes");
 constexpr uint32_t kSphereFace = 0xffffffffu;
 
 // Per-face shading attributes (normals, tangents, uv of the three corners), object order.
