@@ -720,7 +720,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.ovf_stride = pstride;
             run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
             for (uint32_t d = 0; d < D; d++) {
-                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, tblocks, stats, sm); });
+                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, tblocks, pblocks, stats, sm); });
                 run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
             }
             run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
@@ -730,9 +730,13 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             A.ovf_stride = A.E.n;  // the enumeration runs one lane per pixel-sample (its slow path traces rays)
             run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
             A.ovf_stride = pstride;
-            run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
-            run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, tblocks, stats, sm); });
-            run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
+            if (sceneLdsLevel(A.S) == 2) {
+                run(K_RAYS_VISIBLE, units, [&] { launchPairVisibleLds(A, pblocks, stats, sm); });
+            } else {
+                run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
+                run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, tblocks, stats, sm); });
+                run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
+            }
             run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
         } else {
             A.ovf_stride = A.E.n;

@@ -184,6 +184,17 @@ __global__ void k_refit_level(int n_internal, const int32_t* child0, const int32
     atomicAdd(progress, 1u);
 }
 
+// Biased exponent of the quantisation step of a node along one axis: the smallest power of two with 254 steps
+// covering [o, top] (0: the node is flat there and the step is 0).
+__device__ uint32_t stepExponent(float o, float top) {
+    const double extent = (double)top - (double)o;  // exact
+    if (!(extent > 0.0)) return 0;
+    int ex;
+    const double m = frexp(extent / 254.0, &ex);  // extent / 254 = m * 2^ex, m in [0.5, 1)
+    const int biased = (m == 0.5 ? ex - 1 : ex) + 127;
+    return (uint32_t)(biased < 1 ? 1 : (biased > 254 ? 254 : biased));
+}
+
 // Packs the exact fp32 child boxes of a wide node (n of them) into the quantised node format. Along every axis the
 // step is the smallest power of two with 254 steps covering the node, a lower corner is rounded down and an upper
 // corner up to a step, and each rounded corner is then DECODED the way traversal decodes it (nodeCoord) and moved
@@ -199,14 +210,7 @@ __device__ BvhNode packNode(int n, const int32_t* c, const float (*lo)[3], const
         float o = lo[0][a], top = hi[0][a];
         for (int j = 1; j < n; j++) { o = fminf(o, lo[j][a]); top = fmaxf(top, hi[j][a]); }
         nd.origin[a] = o;
-        const double extent = (double)top - (double)o;  // exact
-        uint32_t e = 0;
-        if (extent > 0.0) {
-            int ex;
-            const double m = frexp(extent / 254.0, &ex);  // extent / 254 = m * 2^ex, m in [0.5, 1)
-            int biased = (m == 0.5 ? ex - 1 : ex) + 127;
-            e = (uint32_t)(biased < 1 ? 1 : (biased > 254 ? 254 : biased));
-        }
+        uint32_t e = stepExponent(o, top);
         for (;;) {  // raises the step in the (never observed) case that a corrected corner would not fit a byte
             const float step = nodeStep(e << (8 * a), a);
             bool fits = true;
@@ -245,6 +249,7 @@ __global__ void k_single_leaf(const FBox* leaf_boxes, BvhNode* nodes) {
 // its own two children until the node holds kNodeWidth children or only leaves. The inner children that remain
 // are marked for the next level; binary nodes that were swallowed leave their slots in the output array unused.
 // mark[] starts as 0xffffffff except mark[root] = 0; a launch only reads marks an earlier launch wrote.
+constexpr float kThinSteps = 8.0f;  // a leaf narrower than this many steps of its node gets a node of its own
 __global__ void k_collapse_level(int n_internal, const BinNode* bin, uint32_t* mark, uint32_t level, BvhNode* out,
                                  uint32_t* progress) {
     int i = blockIdx.x * kB + threadIdx.x;
@@ -274,6 +279,28 @@ __global__ void k_collapse_level(int n_internal, const BinNode* bin, uint32_t* m
     uint32_t inner = 0;
     for (int j = 0; j < n; j++)
         if (c[j] >= 0) { mark[c[j]] = level + 1; inner++; }
+    // A leaf that is thin against the node's step along some axis (an axis-aligned wall beside a mesh: 2^-19 thick
+    // in a node that spans the room) would come out of the quantisation many times thicker, and every ray that
+    // starts or ends on the wall would run the fp64 test of its triangles. Such a leaf gets a node of its own
+    // (slot n_internal + primitive index), whose step follows the leaf's own extent: a ray that only meets the
+    // thickened box pays one more node step and never reaches the primitive test.
+    float o[3], top[3];
+    for (int a = 0; a < 3; a++) {
+        o[a] = lo[0][a]; top[a] = hi[0][a];
+        for (int j = 1; j < n; j++) { o[a] = fminf(o[a], lo[j][a]); top[a] = fmaxf(top[a], hi[j][a]); }
+    }
+    for (int j = 0; j < n; j++) {
+        if (c[j] >= 0) continue;
+        bool thin = false;
+        for (int a = 0; a < 3; a++) {
+            const float step = nodeStep(stepExponent(o[a], top[a]) << (8 * a), a);
+            if (hi[j][a] - lo[j][a] < kThinSteps * step) thin = true;
+        }
+        if (!thin) continue;
+        const int32_t slot = n_internal + ~c[j];
+        out[slot] = packNode(1, &c[j], &lo[j], &hi[j]);
+        c[j] = slot;
+    }
     out[i] = packNode(n, c, lo, hi);
     if (inner) atomicAdd(progress, inner);
 }
@@ -314,7 +341,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
     CK(hipMalloc(&progress, sizeof(uint32_t)));
     CK(hipMalloc(&child0, sizeof(int32_t) * n_internal));
     CK(hipMalloc(&child1, sizeof(int32_t) * n_internal));
-    CK(hipMalloc(&nodes, sizeof(BvhNode) * n_internal));
+    CK(hipMalloc(&nodes, sizeof(BvhNode) * ((size_t)n_internal + n)));  // + one slot per primitive for leaves that get a node of their own
     CK(hipMalloc(&bin, sizeof(BinNode) * n_internal));
     CK(hipMalloc(&depth, sizeof(uint32_t) * n_internal));
     CK(hipMalloc(&prims, sizeof(Prim) * n));
@@ -375,7 +402,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
         double hi; memcpy(&hi, &b, 8);
         out->scene_lo[k] = (float)lo; out->scene_hi[k] = (float)hi;
     }
-    out->nodes = nodes; out->prims = prims; out->num_nodes = n_internal;
+    out->nodes = nodes; out->prims = prims; out->num_nodes = n_internal + n;
     nodes = nullptr; prims = nullptr;
 done:
     hipFree(boxes); hipFree(leaf_boxes); hipFree(node_boxes); hipFree(scene); hipFree(keys); hipFree(keys_sorted);

@@ -37,7 +37,8 @@ struct __attribute__((aligned(16))) LdsNode {
 DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
     static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
     constexpr uint32_t kNodeWords = sizeof(BvhNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
-    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : S.num_prims;  // slots of the node array: one per node of the binary tree the wide one is carved from
+    // slots of the node array: one per node of the binary tree the wide one is carved from, then one per primitive
+    const uint32_t n_nodes = (S.num_prims > 1 ? S.num_prims - 1 : 1) + S.num_prims;
     const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
     uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
     for (uint32_t w = threadIdx.x; w < n_nodes * kNodeWords; w += kBlock)
@@ -55,6 +56,7 @@ DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
 // 2 = object table, tree nodes and primitives in LDS
 DEV constexpr uint32_t ldsObjects(int level) { return level >= 1 ? kLdsObjectsTrace : 1; }
 DEV constexpr uint32_t ldsPrims(int level) { return level >= 2 ? kLdsTreePrims : 1; }
+DEV constexpr uint32_t ldsNodes(int level) { return level >= 2 ? 2 * kLdsTreePrims : 1; }
 inline int ldsLevelFor(const DScene& S) {
     if (S.num_objects > kLdsObjectsTrace) return 0;
     return (S.accel == 0 && S.nodes && S.num_prims <= kLdsTreePrims) ? 2 : 1;

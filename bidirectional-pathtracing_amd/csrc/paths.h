@@ -232,7 +232,10 @@ DEV bool lambertSameSide(const ConnVertex& v, d3 a, d3 b) {
 // caller can issue them together with the loads of the two end vertices: one round trip to memory
 // instead of one per step after the connection's arithmetic. Vertex 0 of either subpath (lens,
 // emitter) is never specular.
-constexpr int kWalkAhead = 3;
+#ifndef UBDPT_WALK_AHEAD
+#define UBDPT_WALK_AHEAD 3
+#endif
+constexpr int kWalkAhead = UBDPT_WALK_AHEAD;
 struct WalkAhead {
     double plE[kWalkAhead], peE[kWalkAhead], plL[kWalkAhead], peL[kWalkAhead];
     uint32_t specE, specL;  // bit k: the vertex of step k is specular

@@ -47,7 +47,8 @@ constexpr int kCarryCountSlot = 7;    // the double of the first line that holds
 constexpr int kHitDoubles = 4;        // half a line per subpath
 void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s);
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
-void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
+void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, unsigned small_scene_blocks, bool stats, hipStream_t s);
+void launchPairVisibleLds(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);  // scenes whose tree sits in LDS: set-up + rays + compaction
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s);
 int sceneLdsLevel(const DScene& S);  // 0 = scene in HBM, 1 = object table in LDS, 2 = tree and primitives too
 void launchPairSetup(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);

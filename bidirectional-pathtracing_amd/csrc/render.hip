@@ -915,8 +915,29 @@ void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
             else hipLaunchKernelGGL((K<false, 0u>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);            \
         }                                                                                                      \
     } while (0)
-void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_wf_trace, A, depth);
+// the persistent kernels exist for scenes in HBM (placement 0 and 1); a scene that fits LDS takes the plain ones
+#define UBDPT_LAUNCH_PERSISTENT(K, ...)                                                                        \
+    do {                                                                                                       \
+        const int level_ = ldsLevelFor(A.S);                                                                   \
+        if (stats) {                                                                                           \
+            if (level_ == 1) hipLaunchKernelGGL((K<true, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);  \
+            else hipLaunchKernelGGL((K<true, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);              \
+        } else {                                                                                               \
+            if (level_ == 1) hipLaunchKernelGGL((K<false, 1>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__); \
+            else hipLaunchKernelGGL((K<false, 0>), dim3(blocks), dim3(kBlock), 0, s, __VA_ARGS__);             \
+        }                                                                                                      \
+    } while (0)
+void launchWfTrace(const RenderArgs& A, uint32_t depth, unsigned blocks, unsigned small_scene_blocks, bool stats, hipStream_t s) {
+    if (ldsLevelFor(A.S) == 2) {
+        if (stats) hipLaunchKernelGGL(k_wf_trace_lds<true>, dim3(small_scene_blocks), dim3(kBlock), 0, s, A, depth);
+        else hipLaunchKernelGGL(k_wf_trace_lds<false>, dim3(small_scene_blocks), dim3(kBlock), 0, s, A, depth);
+        return;
+    }
+    UBDPT_LAUNCH_PERSISTENT(k_wf_trace, A, depth);
+}
+void launchPairVisibleLds(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
+    if (stats) hipLaunchKernelGGL(k_pair_visible_lds<true>, dim3(blocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_visible_lds<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchWfShade(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
     UBDPT_LAUNCH_LDS(k_wf_shade, kLdsObjectsShade, A, depth);
@@ -927,7 +948,7 @@ void launchPairSetup(const RenderArgs& A, unsigned blocks, bool stats, hipStream
     else hipLaunchKernelGGL(k_pair_setup<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 void launchRaysVisible(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
-    UBDPT_LAUNCH_TRACE(k_rays_visible, A);
+    UBDPT_LAUNCH_PERSISTENT(k_rays_visible, A);
 }
 void launchPairCompact(const RenderArgs& A, unsigned blocks, hipStream_t s) {
     hipLaunchKernelGGL(k_pair_compact, dim3(blocks), dim3(kBlock), 0, s, A);

@@ -300,7 +300,7 @@ template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
-    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsNodes(LDS_LEVEL)];
     __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
     if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);

@@ -70,6 +70,13 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // next, so its load completes under the wait for the tree nodes the walking lanes fetch anyway: refilling never
 // stalls the wave. Leaves are tested when kLeafBatch lanes hold one (or nothing else can make progress, or a
 // lane has waited kLeafWait node steps), so the fp64 primitive test runs for many lanes at once.
+// Where a wave's time goes (2 M-triangle scene, wall-clock stamps inside the loop, -DUBDPT_WAVE_TIMES build): an
+// iteration takes about 4 us with 16 waves per CU; 34 % of it is spent waiting for the node and the primitive,
+// 54 % in the arithmetic between the waits (node step 16 %, local ray 2 %, primitive test 12 %, bounding-sphere gate
+// + pop + store 22 %), 12 % on arrivals and feeding. After the queue runs dry a wave lives another 0.2 ms on
+// average (its longest ray). Measured and not kept: requesting the next node or primitive at the end of an
+// iteration and using it in the next (one wait per iteration instead of two, but one step per lane and iteration
+// and 12 more live registers): 212 against 239 Mpaths/s; five waves per SIMD: 12 to 34 registers spilled.
 #ifndef UBDPT_RAY_CHUNK
 #define UBDPT_RAY_CHUNK 256
 #endif
@@ -145,7 +152,7 @@ template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
-    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsNodes(LDS_LEVEL)];
     __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
     if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
@@ -490,7 +497,7 @@ template <bool STATS, int LDS_LEVEL>
 __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(RenderArgs A0) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
-    __shared__ LdsNode s_nodes[ldsPrims(LDS_LEVEL)];
+    __shared__ LdsNode s_nodes[ldsNodes(LDS_LEVEL)];
     __shared__ Prim s_prims[ldsPrims(LDS_LEVEL)];
     RenderArgs A = A0;
     if (LDS_LEVEL >= 1) A.S.objects = stageObjects(A0.S, s_objects);
@@ -570,6 +577,92 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(
                 }
             }
         }
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// ---- scenes whose tree and primitives sit in LDS (a few dozen primitives): one ray per lane ------------------------
+// A ray crosses such a tree in two or three steps out of LDS and the rays of a wave take about equally long, so the
+// queue of the persistent waves and the ray records between set-up and traversal cost more than they save (measured on
+// a box of 14 primitives at 512 x 512: trace 0.64 -> 0.43 ms per launch, connection visibility 6.0 -> 1.9 ms per batch).
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace_lds(RenderArgs A0, uint32_t depth) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ DObject s_objects[ldsObjects(2)];
+    __shared__ LdsNode s_nodes[ldsNodes(2)];
+    __shared__ Prim s_prims[ldsPrims(2)];
+    RenderArgs A = A0;
+    A.S.objects = stageObjects(A0.S, s_objects);
+    stageTree(A.S, s_nodes, s_prims);
+    const DScene& S = A.S;
+    const uint64_t n2 = 2 * A.E.n;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint64_t total = depth == 0 ? n2 : (uint64_t)A.wf_count[(uint64_t)depth * kWfQStride];
+    const uint32_t* q = A.wf_trace_q + (uint64_t)(depth & 1) * n2;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
+    Tally ty;
+    for (uint64_t j = gid; j < total; j += nthreads) {
+        const uint32_t id = depth == 0 ? (uint32_t)j : q[j];
+        const double* p = A.carry + (uint64_t)id * kCarryDoubles;
+        if ((reinterpret_cast<const uint32_t*>(p + kCarryCountSlot)[0] & 0xffu) == 0) continue;  // no subpath under this id
+        Ray ray;
+        ray.o = mk3(p[0], p[1], p[2]);
+        ray.d = mk3(p[3], p[4], p[5]);
+        storeHit(A, id, closestHit<STATS>(S, ray, st, ty));
+    }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
+}
+
+// Set-up tests, shadow ray and compaction of the visible pairs in one kernel (k_pair_setup + k_rays_visible +
+// k_pair_compact of the large scenes).
+template <bool STATS>
+__global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible_lds(RenderArgs A0) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    __shared__ uint32_t s_wave[kBlock / 64];
+    __shared__ uint32_t s_base;
+    __shared__ DObject s_objects[ldsObjects(2)];
+    __shared__ LdsNode s_nodes[ldsNodes(2)];
+    __shared__ Prim s_prims[ldsPrims(2)];
+    RenderArgs A = A0;
+    A.S.objects = stageObjects(A0.S, s_objects);
+    stageTree(A.S, s_nodes, s_prims);
+    const DScene& S = A.S;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + tid;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    unsigned long long total = *A.pair_count;
+    if (total > A.pair_capacity) total = A.pair_capacity;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
+    Tally ty;
+    for (unsigned long long base = (unsigned long long)blockIdx.x * kBlock; base < total; base += nthreads) {
+        const unsigned long long j = base + tid;
+        bool ok = false;
+        uint64_t p = 0;
+        if (j < total) {
+            p = A.pairs[j];
+            const uint32_t s = (uint32_t)((p >> 8) & 0xff), t = (uint32_t)(p & 0xff);
+            const uint64_t i = p >> 16;
+            if (s != 0) {
+                const d3 lpos = A.L.ld3(F_POS, s - 1, i);
+                const d3 epos = A.E.ld3(F_POS, t - 1, i);
+                ok = true;
+                if (t == 1) {
+                    uint32_t tx, tyy;
+                    ok = t1Pixel(S, lpos, epos, tx, tyy);
+                }
+                if (ok) {
+                    d3 ce = lpos - epos;
+                    ce = ce / sqrt(dot(ce, ce));
+                    if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) ok = false;
+                }
+                if (ok) ok = visible<STATS>(S, lpos, epos, st, ty);
+            }
+        }
+        const uint32_t pos = blockAppend(ok, A.vis_count, s_wave, &s_base);
+        if (ok) A.vis_pairs[pos] = p;
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
