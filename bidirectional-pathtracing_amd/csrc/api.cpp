@@ -105,6 +105,7 @@ struct ubdpt_context {
     DTexture* d_textures = nullptr;
     uint8_t* d_texels = nullptr;
     BvhNode* d_nodes = nullptr;
+    ExactNode* d_xnodes = nullptr;
     Prim* d_prims = nullptr;
     DScene S{};
 
@@ -248,7 +249,7 @@ struct ubdpt_context {
         if (clear_ev) hipEventDestroy(clear_ev);
         for (auto& e : event_pool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
         hipFree(d_objects); hipFree(d_emitters); hipFree(d_face_pos); hipFree(d_face_attr); hipFree(d_face_prob); hipFree(d_face_cdf);
-        hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
+        hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_xnodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         if (h_staging) { hipHostFree(h_staging); h_staging = nullptr; }
         if (h_noalloc_counters) { hipHostFree(h_noalloc_counters); h_noalloc_counters = nullptr; }
         for (auto& b : lanes) {
@@ -398,15 +399,16 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
     hipFree(d_unsorted);
     HIPCK(c, be);
     c->d_nodes = br.nodes;
+    c->d_xnodes = br.xnodes;
     c->d_prims = br.prims;
 
     DScene& S = c->S;
     S.objects = c->d_objects; S.emitters = c->d_emitters; S.face_pos = c->d_face_pos; S.face_attr = c->d_face_attr;
     S.face_prob = c->d_face_prob; S.face_cdf = c->d_face_cdf; S.textures = c->d_textures; S.texels = c->d_texels;
-    S.nodes = c->d_nodes; S.prims = c->d_prims;
+    S.nodes = c->d_nodes; S.xnodes = c->d_xnodes; S.prims = c->d_prims;
     S.num_objects = sd->num_objects; S.num_emitters = (uint32_t)emitters.size(); S.num_prims = (uint32_t)prims.size();
     S.accel = c->opt.accel; S.num_faces = sd->num_faces;
-    S.node_stride = (uint32_t)sizeof(BvhNode); S.pad0 = 0;
+    S.node_stride = (uint32_t)sizeof(BvhNode); S.xnode_stride = (uint32_t)sizeof(ExactNode);
 
     // uengine/ucamera.cpp:3-14,67-70 and uengine/ubdptrenderer.cpp:7-33
     const ubdpt_camera& cam = sd->camera;

@@ -237,11 +237,23 @@ __device__ BvhNode packNode(int n, const int32_t* c, const float (*lo)[3], const
     return nd;
 }
 
-__global__ void k_single_leaf(const FBox* leaf_boxes, BvhNode* nodes) {
+// The full-precision twin of a wide node (small scenes only): the same children, fp32 boxes as they are.
+__device__ ExactNode exactNode(int n, const int32_t* c, const float (*lo)[3], const float (*hi)[3]) {
+    ExactNode nd;
+    for (int j = 0; j < kNodeWidth; j++) {
+        for (int k = 0; k < 3; k++) { nd.lo[j][k] = j < n ? lo[j][k] : 0.0f; nd.hi[j][k] = j < n ? hi[j][k] : 0.0f; }
+        nd.child[j] = j < n ? c[j] : kEmptyChild;
+    }
+    for (int& x : nd.pad) x = 0;
+    return nd;
+}
+
+__global__ void k_single_leaf(const FBox* leaf_boxes, BvhNode* nodes, ExactNode* xnodes) {
     int32_t c[1] = {~0};
     float lo[1][3], hi[1][3];
     for (int k = 0; k < 3; k++) { lo[0][k] = leaf_boxes[0].lo[k]; hi[0][k] = leaf_boxes[0].hi[k]; }
     nodes[0] = packNode(1, c, lo, hi);
+    if (xnodes) xnodes[0] = exactNode(1, c, lo, hi);
 }
 
 // One top-down level of the collapse into wide nodes. A binary node marked with `level` becomes a wide node with
@@ -251,7 +263,7 @@ __global__ void k_single_leaf(const FBox* leaf_boxes, BvhNode* nodes) {
 // mark[] starts as 0xffffffff except mark[root] = 0; a launch only reads marks an earlier launch wrote.
 constexpr float kThinSteps = 8.0f;  // a leaf narrower than this many steps of its node gets a node of its own
 __global__ void k_collapse_level(int n_internal, const BinNode* bin, uint32_t* mark, uint32_t level, BvhNode* out,
-                                 uint32_t* progress) {
+                                 ExactNode* xout, uint32_t* progress) {
     int i = blockIdx.x * kB + threadIdx.x;
     if (i >= n_internal) return;
     if (mark[i] != level) return;
@@ -279,6 +291,7 @@ __global__ void k_collapse_level(int n_internal, const BinNode* bin, uint32_t* m
     uint32_t inner = 0;
     for (int j = 0; j < n; j++)
         if (c[j] >= 0) { mark[c[j]] = level + 1; inner++; }
+    if (xout) xout[i] = exactNode(n, c, lo, hi);
     // A leaf that is thin against the node's step along some axis (an axis-aligned wall beside a mesh: 2^-19 thick
     // in a node that spans the room) would come out of the quantisation many times thicker, and every ray that
     // starts or ends on the wall would run the fp64 test of its triangles. Such a leaf gets a node of its own
@@ -312,7 +325,7 @@ __global__ void k_collapse_level(int n_internal, const BinNode* bin, uint32_t* m
 hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uint32_t n, hipStream_t s,
                      BvhBuildResult* out) {
     hipError_t err = hipSuccess;
-    out->nodes = nullptr; out->prims = nullptr; out->num_nodes = 0;
+    out->nodes = nullptr; out->xnodes = nullptr; out->prims = nullptr; out->num_nodes = 0;
     for (int k = 0; k < 3; k++) { out->scene_lo[k] = 0; out->scene_hi[k] = 0; }
     if (n == 0) return hipSuccess;
 
@@ -324,6 +337,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
     void* sort_tmp = nullptr;
     size_t sort_bytes = 0;
     BvhNode* nodes = nullptr; Prim* prims = nullptr;
+    ExactNode* xnodes = nullptr;
     uint32_t n_internal = n > 1 ? n - 1 : 1;
     unsigned g = (n + kB - 1) / kB;
     unsigned long long scene_init[6];
@@ -342,6 +356,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
     CK(hipMalloc(&child0, sizeof(int32_t) * n_internal));
     CK(hipMalloc(&child1, sizeof(int32_t) * n_internal));
     CK(hipMalloc(&nodes, sizeof(BvhNode) * ((size_t)n_internal + n)));  // + one slot per primitive for leaves that get a node of their own
+    if (n <= kExactTreePrims) CK(hipMalloc(&xnodes, sizeof(ExactNode) * n_internal));
     CK(hipMalloc(&bin, sizeof(BinNode) * n_internal));
     CK(hipMalloc(&depth, sizeof(uint32_t) * n_internal));
     CK(hipMalloc(&prims, sizeof(Prim) * n));
@@ -355,7 +370,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
     CK(hipcub::DeviceRadixSort::SortPairs(sort_tmp, sort_bytes, keys, keys_sorted, idx, idx_sorted, (int)n, 0, 63, s));
     hipLaunchKernelGGL(k_gather, dim3(g), dim3(kB), 0, s, d_prims_unsorted, boxes, idx_sorted, n, scene, prims, leaf_boxes);
     if (n == 1) {
-        hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(1), 0, s, leaf_boxes, nodes);
+        hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(1), 0, s, leaf_boxes, nodes, xnodes);
     } else {
         unsigned gi = (n_internal + kB - 1) / kB;
         hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(kB), 0, s, keys_sorted, (int)n, child0, child1);
@@ -383,7 +398,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
                 before = seen;
                 for (int rep = 0; rep < 8; rep++, lv++)
                     hipLaunchKernelGGL(k_collapse_level, dim3(gi), dim3(kB), 0, s, (int)n_internal, bin, depth, lv, nodes,
-                                       progress);
+                                       xnodes, progress);
                 CK(hipMemcpyAsync(&seen, progress, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
                 CK(hipStreamSynchronize(s));
             }
@@ -402,12 +417,12 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
         double hi; memcpy(&hi, &b, 8);
         out->scene_lo[k] = (float)lo; out->scene_hi[k] = (float)hi;
     }
-    out->nodes = nodes; out->prims = prims; out->num_nodes = n_internal + n;
-    nodes = nullptr; prims = nullptr;
+    out->nodes = nodes; out->xnodes = xnodes; out->prims = prims; out->num_nodes = n_internal + n;
+    nodes = nullptr; xnodes = nullptr; prims = nullptr;
 done:
     hipFree(boxes); hipFree(leaf_boxes); hipFree(node_boxes); hipFree(scene); hipFree(keys); hipFree(keys_sorted);
     hipFree(idx); hipFree(idx_sorted); hipFree(ready); hipFree(progress); hipFree(child0); hipFree(child1);
-    hipFree(sort_tmp); hipFree(nodes); hipFree(prims); hipFree(bin); hipFree(depth);
+    hipFree(sort_tmp); hipFree(nodes); hipFree(xnodes); hipFree(prims); hipFree(bin); hipFree(depth);
     return err;
 }
 

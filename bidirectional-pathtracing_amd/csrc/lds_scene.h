@@ -13,7 +13,7 @@ namespace ub {
 
 constexpr uint32_t kLdsObjectsShade = 64;  // shading kernels hold 2 workgroups per CU
 constexpr uint32_t kLdsObjectsTrace = 32;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
-constexpr uint32_t kLdsTreePrims = 48;
+constexpr uint32_t kLdsTreePrims = kExactTreePrims;
 
 // Every thread of the workgroup must call this; the returned pointer replaces DScene::objects.
 DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
@@ -29,17 +29,17 @@ DEV const DObject* stageObjects(const DScene& S, DObject* lds) {
 // In LDS a node is followed by 16 bytes of padding: with the power-of-two stride of the HBM layout the lanes of
 // a wave that read the same field of different nodes would all hit the same few banks.
 struct __attribute__((aligned(16))) LdsNode {
-    BvhNode n;
+    ExactNode n;
     uint32_t pad[4];
 };
 
-// Every thread of the workgroup must call this; S then points at the LDS copies of nodes and primitives.
+// Every thread of the workgroup must call this; S.xnodes and S.prims then point at the LDS copies of the
+// full-precision tree and the primitives (a kernel that calls this walks the tree with EXACT = true).
 DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
-    static_assert(sizeof(BvhNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
-    constexpr uint32_t kNodeWords = sizeof(BvhNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
-    // slots of the node array: one per node of the binary tree the wide one is carved from, then one per primitive
-    const uint32_t n_nodes = (S.num_prims > 1 ? S.num_prims - 1 : 1) + S.num_prims;
-    const uint4* src = reinterpret_cast<const uint4*>(S.nodes);
+    static_assert(sizeof(ExactNode) % 16 == 0 && sizeof(LdsNode) % 16 == 0 && sizeof(Prim) % 16 == 0, "copied in 16-byte words");
+    constexpr uint32_t kNodeWords = sizeof(ExactNode) / 16, kLdsNodeWords = sizeof(LdsNode) / 16;
+    const uint32_t n_nodes = S.num_prims > 1 ? S.num_prims - 1 : 1;  // slots of the node array: one per node of the binary tree
+    const uint4* src = reinterpret_cast<const uint4*>(S.xnodes);
     uint4* dst = reinterpret_cast<uint4*>(lds_nodes);
     for (uint32_t w = threadIdx.x; w < n_nodes * kNodeWords; w += kBlock)
         dst[(w / kNodeWords) * kLdsNodeWords + (w % kNodeWords)] = src[w];
@@ -47,8 +47,8 @@ DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
     dst = reinterpret_cast<uint4*>(lds_prims);
     for (uint32_t w = threadIdx.x; w < S.num_prims * (uint32_t)(sizeof(Prim) / 16); w += kBlock) dst[w] = src[w];
     __syncthreads();
-    S.nodes = &lds_nodes[0].n;
-    S.node_stride = (uint32_t)sizeof(LdsNode);
+    S.xnodes = &lds_nodes[0].n;
+    S.xnode_stride = (uint32_t)sizeof(LdsNode);
     S.prims = lds_prims;
 }
 
@@ -56,10 +56,10 @@ DEV void stageTree(DScene& S, LdsNode* lds_nodes, Prim* lds_prims) {
 // 2 = object table, tree nodes and primitives in LDS
 DEV constexpr uint32_t ldsObjects(int level) { return level >= 1 ? kLdsObjectsTrace : 1; }
 DEV constexpr uint32_t ldsPrims(int level) { return level >= 2 ? kLdsTreePrims : 1; }
-DEV constexpr uint32_t ldsNodes(int level) { return level >= 2 ? 2 * kLdsTreePrims : 1; }
+DEV constexpr uint32_t ldsNodes(int level) { return level >= 2 ? kLdsTreePrims : 1; }
 inline int ldsLevelFor(const DScene& S) {
     if (S.num_objects > kLdsObjectsTrace) return 0;
-    return (S.accel == 0 && S.nodes && S.num_prims <= kLdsTreePrims) ? 2 : 1;
+    return (S.accel == 0 && S.xnodes && S.num_prims <= kLdsTreePrims) ? 2 : 1;
 }
 
 }  // namespace ub

@@ -90,6 +90,7 @@ void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma
 // tree order and `nodes_out` the tree (max(1, n-1) nodes, root = node 0).
 struct BvhBuildResult {
     BvhNode* nodes;   // device, owned by caller after return
+    ExactNode* xnodes; // device, owned by caller after return; null above kExactTreePrims primitives
     Prim* prims;      // device, owned by caller after return
     uint32_t num_nodes;
     float scene_lo[3], scene_hi[3];

@@ -37,17 +37,18 @@ DEV Stack makeStack(int32_t* lds_base, int32_t* ovf, uint64_t ovf_stride, uint64
     return st;
 }
 
-template <bool STATS>
+// EXACT: the kernel has staged the full-precision tree in LDS (lds_scene.h) and walks that one
+template <bool STATS, bool EXACT = false>
 DEV Closest closestHit(const DScene& S, const Ray& r, Stack& st, Tally& ty) {
     if (STATS) ty.closest++;
     if (S.accel == 1) return closestHitLinear(S, r, STATS ? &ty.tc : nullptr);
-    return closestHitBvh(S, r, st, STATS ? &ty.tc : nullptr);
+    return closestHitBvh<EXACT>(S, r, st, STATS ? &ty.tc : nullptr);
 }
-template <bool STATS>
+template <bool STATS, bool EXACT = false>
 DEV bool visible(const DScene& S, d3 p0, d3 p1, Stack& st, Tally& ty) {
     if (STATS) ty.shadow++;
     if (S.accel == 1) return visibleLinear(S, p0, p1, STATS ? &ty.tc : nullptr);
-    return visibleBvh(S, p0, p1, st, STATS ? &ty.tc : nullptr);
+    return visibleBvh<EXACT>(S, p0, p1, st, STATS ? &ty.tc : nullptr);
 }
 
 DEV void flushTally(const Tally& ty, unsigned long long* counters, uint32_t eye_v, uint32_t light_v) {

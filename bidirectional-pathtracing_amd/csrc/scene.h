@@ -59,6 +59,18 @@ struct __attribute__((aligned(16))) BvhNode {
 };
 static_assert(sizeof(BvhNode) == (kNodeWidth == 4 ? 64 : 96), "BvhNode is 64 or 96 bytes");
 constexpr int32_t kEmptyChild = 0x7fffffff;
+// The same node with full fp32 child boxes, built beside the quantised tree for scenes of at most kExactTreePrims
+// primitives, whose tree is copied to LDS by the kernels that walk it: there node bytes cost nothing, and a room
+// of axis-aligned walls is all thin leaves (6.1 node visits per ray through the quantised tree of a 14-primitive
+// box, 2.5 through this one).
+constexpr uint32_t kExactTreePrims = 48;
+struct __attribute__((aligned(16))) ExactNode {
+    float lo[kNodeWidth][3];
+    float hi[kNodeWidth][3];
+    int32_t child[kNodeWidth];
+    int32_t pad[kNodeWidth == 4 ? 4 : 8];
+};
+static_assert(sizeof(ExactNode) == (kNodeWidth == 4 ? 128 : 256), "ExactNode is 128 or 256 bytes");
 // step of a node along axis a, and the decoded coordinate of byte q: origin + q * step, one fp32 multiplication
 // (exact) and one addition, never fused; builder and traversal both go through these two functions
 __host__ __device__ inline float nodeStep(uint32_t exps, int a) {
@@ -107,10 +119,11 @@ struct DScene {
     const DTexture* textures;
     const uint8_t* texels;
     const BvhNode* nodes;
+    const ExactNode* xnodes;  // full-precision twin of `nodes` (small scenes only, else null); the LDS copy in kernels that stage the tree
     const Prim* prims;
     uint32_t num_objects, num_emitters, num_prims, accel;
-    uint32_t node_stride;  // bytes between two tree nodes: sizeof(BvhNode) in HBM, padded in an LDS copy
-    uint32_t pad0;
+    uint32_t node_stride;   // bytes between two tree nodes: sizeof(BvhNode) in HBM
+    uint32_t xnode_stride;  // the same for xnodes: sizeof(ExactNode) in HBM, padded in an LDS copy
     uint64_t num_faces;
 
     // UBDPTRenderer members (uengine/ubdptrenderer.h:54-79)

@@ -210,23 +210,9 @@ DEV void sortPair(float& ta, int32_t& ca, float& tb, int32_t& cb) {
 DEV BvhNode loadNode(const DScene& S, int32_t node) {
     return *reinterpret_cast<const BvhNode*>(reinterpret_cast<const char*>(S.nodes) + (size_t)node * S.node_stride);
 }
-DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
-    if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
-
+// entry distances of the children, near to far, then: the nearest child that is hit is returned, the others pushed
+DEV int32_t sortAndPush(float (&t)[kNodeWidth], int32_t (&c)[kNodeWidth], Stack& st, TraceCounters* tc) {
     const float inf = __builtin_inff();
-    float t[kNodeWidth];
-    int32_t c[kNodeWidth];
-    const float sx = nodeStep(nd.exps, 0), sy = nodeStep(nd.exps, 1), sz = nodeStep(nd.exps, 2);
-#pragma unroll
-    for (int k = 0; k < kNodeWidth; k++) {
-        c[k] = nd.child[k];
-        const int w = k >> 2, sh = 8 * (k & 3);
-        const float lo[3] = {nodeCoord(nd.origin[0], (nd.q[0][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[1][w] >> sh) & 0xffu, sy),
-                             nodeCoord(nd.origin[2], (nd.q[2][w] >> sh) & 0xffu, sz)};
-        const float hi[3] = {nodeCoord(nd.origin[0], (nd.q[3][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[4][w] >> sh) & 0xffu, sy),
-                             nodeCoord(nd.origin[2], (nd.q[5][w] >> sh) & 0xffu, sz)};
-        if (!(c[k] != kEmptyChild && slabF(lo, hi, q, tmax, t[k]))) t[k] = inf;
-    }
     // entry distances are finite for a hit (the ray parameter interval is clipped to [.., tmax]); sort near to far
     // with a comparator network (5 comparators for four, 19 for eight), misses (inf) end up last
     if (kNodeWidth == 4) {
@@ -246,8 +232,41 @@ DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st,
     if (t[0] < inf) return c[0];
     return st.sp ? st.pop() : kTraversalDone;
 }
-DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, bool /*ordered*/,
-                    TraceCounters* tc) {
+DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
+    if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
+    const float inf = __builtin_inff();
+    float t[kNodeWidth];
+    int32_t c[kNodeWidth];
+    const float sx = nodeStep(nd.exps, 0), sy = nodeStep(nd.exps, 1), sz = nodeStep(nd.exps, 2);
+#pragma unroll
+    for (int k = 0; k < kNodeWidth; k++) {
+        c[k] = nd.child[k];
+        const int w = k >> 2, sh = 8 * (k & 3);
+        const float lo[3] = {nodeCoord(nd.origin[0], (nd.q[0][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[1][w] >> sh) & 0xffu, sy),
+                             nodeCoord(nd.origin[2], (nd.q[2][w] >> sh) & 0xffu, sz)};
+        const float hi[3] = {nodeCoord(nd.origin[0], (nd.q[3][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[4][w] >> sh) & 0xffu, sy),
+                             nodeCoord(nd.origin[2], (nd.q[5][w] >> sh) & 0xffu, sz)};
+        if (!(c[k] != kEmptyChild && slabF(lo, hi, q, tmax, t[k]))) t[k] = inf;
+    }
+    return sortAndPush(t, c, st, tc);
+}
+DEV int32_t descendExact(const ExactNode& nd, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
+    if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
+    const float inf = __builtin_inff();
+    float t[kNodeWidth];
+    int32_t c[kNodeWidth];
+#pragma unroll
+    for (int k = 0; k < kNodeWidth; k++) {
+        c[k] = nd.child[k];
+        if (!(c[k] != kEmptyChild && slabF(nd.lo[k], nd.hi[k], q, tmax, t[k]))) t[k] = inf;
+    }
+    return sortAndPush(t, c, st, tc);
+}
+// EXACT: walk the full-precision twin of the tree (S.xnodes)
+template <bool EXACT>
+DEV int32_t descendIn(const DScene& S, int32_t node, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
+    if (EXACT)
+        return descendExact(*reinterpret_cast<const ExactNode*>(reinterpret_cast<const char*>(S.xnodes) + (size_t)node * S.xnode_stride), q, tmax, st, tc);
     return descendNode(loadNode(S, node), q, tmax, st, tc);
 }
 
@@ -259,6 +278,7 @@ DEV int32_t descend(const DScene& S, int32_t node, const RayF& q, float tmax, St
 // then false is returned and `best` holds the closest candidate found up to there. Calling again
 // with that `best` (the walk restarts at the root, pruned by best.d) gives the same final answer as
 // one unlimited call: the result is the lexicographic minimum over all primitives, whatever the order.
+template <bool EXACT = false>
 DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc, uint32_t budget, Closest& best) {
     if (S.num_prims == 0) return true;
     LocalCache c;
@@ -271,7 +291,7 @@ DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack& st, TraceCoun
     for (;;) {
         while (node >= 0 && node != kTraversalDone) {
             if (steps++ >= budget) return false;
-            node = descend(S, node, q, tmax, st, true, tc);
+            node = descendIn<EXACT>(S, node, q, tmax, st, tc);
         }
         if (node == kTraversalDone) break;
         if (steps++ >= budget) return false;
@@ -282,10 +302,11 @@ DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack& st, TraceCoun
     }
     return true;
 }
+template <bool EXACT = false>
 DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc) {
     Closest best;
     best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
-    closestHitBvhBudget(S, r, st, tc, 0xffffffffu, best);
+    closestHitBvhBudget<EXACT>(S, r, st, tc, 0xffffffffu, best);
     return best;
 }
 
@@ -295,6 +316,7 @@ DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack& st, TraceCounter
 // the rays that exceeded it again, together, keeps far more lanes busy in both rounds. The answer
 // does not depend on the order the tree is walked in, so a second run from the root is exact.
 enum { kBlocked = 0, kVisible = 1, kOutOfBudget = 2 };
+template <bool EXACT = false>
 DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc, uint32_t budget) {
     double dist = length(p1 - p0);
     Ray r;
@@ -311,7 +333,7 @@ DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters
     for (;;) {
         while (node >= 0 && node != kTraversalDone) {
             if (steps++ >= budget) return kOutOfBudget;
-            node = descend(S, node, q, tmax, st, false, tc);
+            node = descendIn<EXACT>(S, node, q, tmax, st, tc);
         }
         if (node == kTraversalDone) break;
         if (steps++ >= budget) return kOutOfBudget;
@@ -323,8 +345,9 @@ DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters
 }
 
 // UScene::visibility through the LBVH: true when nothing blocks p0 -> p1.
+template <bool EXACT = false>
 DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc) {
-    return visibleBvhBudget(S, p0, p1, st, tc, 0xffffffffu) == kVisible;
+    return visibleBvhBudget<EXACT>(S, p0, p1, st, tc, 0xffffffffu) == kVisible;
 }
 
 // ---- linear-scan accelerator: the reference's own loops, for cross-checking the tree --------------

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_tail(RenderArgs A0, uint32_t dept
         for (;;) {
             Ray ray;
             ray.o = cy.pos; ray.d = cy.dir;
-            Closest hit = closestHit<STATS>(S, ray, st, ty);
+            Closest hit = closestHit<STATS, (LDS_LEVEL >= 2)>(S, ray, st, ty);
             if (hit.object < 0) break;
             int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
             if (light && lobe == LOBE_NONE) break;

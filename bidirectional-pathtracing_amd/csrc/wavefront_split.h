@@ -89,6 +89,9 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 #ifndef UBDPT_LEAF_WAIT
 #define UBDPT_LEAF_WAIT 3
 #endif
+#ifndef UBDPT_DRAIN_EAGER
+#define UBDPT_DRAIN_EAGER 0
+#endif
 constexpr uint32_t kRayChunk = UBDPT_RAY_CHUNK;
 constexpr int kRefillMin = UBDPT_REFILL_MIN;
 constexpr int kLeafBatch = UBDPT_LEAF_BATCH;
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
         WT_STAMP(3)
 #else
         if (state == ST_ACTIVE && node >= 0) {
-            node = descend(S, node, rq, tmax, st, true, tc);
+            node = descendIn<(LDS_LEVEL >= 2)>(S, node, rq, tmax, st, tc);
             if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
         }
 #endif
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
         const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
         if (leaf_m != 0) {
             const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
-            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait || (UBDPT_DRAIN_EAGER && feed.drained)) {
                 leaf_wait = 0;
 #ifdef UBDPT_WAVE_TIMES
                 wt_leaf++;
@@ -558,14 +561,14 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(
         if (act_m == 0) continue;
         // (3) node steps
         if (state == ST_ACTIVE && node >= 0) {
-            node = descend(S, node, rq, tmax, st, false, tc);
+            node = descendIn<(LDS_LEVEL >= 2)>(S, node, rq, tmax, st, tc);
             if (node == kTraversalDone) { A.ray_flag[idx] = 1; state = ST_IDLE; }
         }
         // (4) primitive tests
         const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
         if (leaf_m != 0) {
             const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
-            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait || (UBDPT_DRAIN_EAGER && feed.drained)) {
                 leaf_wait = 0;
                 if (state == ST_ACTIVE && node < 0) {
                     if (STATS) { tc->prims++; countWaveStep(tc->wave_prims); }
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_wf_trace_lds(Rend
         Ray ray;
         ray.o = mk3(p[0], p[1], p[2]);
         ray.d = mk3(p[3], p[4], p[5]);
-        storeHit(A, id, closestHit<STATS>(S, ray, st, ty));
+        storeHit(A, id, closestHit<STATS, true>(S, ray, st, ty));
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_TRACE_WAVES) void k_pair_visible_lds(
                     ce = ce / sqrt(dot(ce, ce));
                     if ((dot(ce, t == 1 ? lensNormal(S) : A.E.ld3(F_NG, t - 1, i)) <= 0) || (dot(-ce, A.L.ld3(F_NG, s - 1, i)) <= 0)) ok = false;
                 }
-                if (ok) ok = visible<STATS>(S, lpos, epos, st, ty);
+                if (ok) ok = visible<STATS, true>(S, lpos, epos, st, ty);
             }
         }
         const uint32_t pos = blockAppend(ok, A.vis_count, s_wave, &s_base);
