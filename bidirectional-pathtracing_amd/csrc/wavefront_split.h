@@ -76,7 +76,8 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // + pop + store 22 %), 12 % on arrivals and feeding. After the queue runs dry a wave lives another 0.2 ms on
 // average (its longest ray). Measured and not kept: requesting the next node or primitive at the end of an
 // iteration and using it in the next (one wait per iteration instead of two, but one step per lane and iteration
-// and 12 more live registers): 212 against 239 Mpaths/s; five waves per SIMD: 12 to 34 registers spilled.
+// and 12 more live registers): 212 against 239 Mpaths/s; five waves per SIMD: 12 to 34 registers spilled; testing
+// leaves at once when the queue has run dry instead of waiting for a batch: no difference (three alternating runs).
 #ifndef UBDPT_RAY_CHUNK
 #define UBDPT_RAY_CHUNK 256
 #endif
@@ -88,9 +89,6 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 #endif
 #ifndef UBDPT_LEAF_WAIT
 #define UBDPT_LEAF_WAIT 3
-#endif
-#ifndef UBDPT_DRAIN_EAGER
-#define UBDPT_DRAIN_EAGER 0
 #endif
 constexpr uint32_t kRayChunk = UBDPT_RAY_CHUNK;
 constexpr int kRefillMin = UBDPT_REFILL_MIN;
@@ -281,7 +279,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
         const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
         if (leaf_m != 0) {
             const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
-            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait || (UBDPT_DRAIN_EAGER && feed.drained)) {
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
                 leaf_wait = 0;
 #ifdef UBDPT_WAVE_TIMES
                 wt_leaf++;
@@ -568,7 +566,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_rays_visible(
         const unsigned long long leaf_m = __ballot(state == ST_ACTIVE && node < 0);
         if (leaf_m != 0) {
             const unsigned long long inner_m = __ballot(state == ST_ACTIVE && node >= 0);
-            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait || (UBDPT_DRAIN_EAGER && feed.drained)) {
+            if ((int)__popcll(leaf_m) >= kLeafBatch || inner_m == 0 || ++leaf_wait >= kLeafWait) {
                 leaf_wait = 0;
                 if (state == ST_ACTIVE && node < 0) {
                     if (STATS) { tc->prims++; countWaveStep(tc->wave_prims); }
