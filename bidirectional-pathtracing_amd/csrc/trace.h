@@ -270,84 +270,54 @@ DEV int32_t descendIn(const DScene& S, int32_t node, const RayF& q, float tmax, 
     return descendNode(loadNode(S, node), q, tmax, st, tc);
 }
 
-// UScene::intersectionPoint through the LBVH. Returns the lexicographically smallest (d, object, face).
-// while-while form: every lane of the wave descends until it holds a leaf (or is done), then the
-// fp64 primitive tests of all lanes run together.
-// `best` goes in as the closest candidate known so far (object -1, d = +inf: none) and comes out as
-// the closest hit, unless the walk needed more than `budget` steps (node visits + primitive tests):
-// then false is returned and `best` holds the closest candidate found up to there. Calling again
-// with that `best` (the walk restarts at the root, pruned by best.d) gives the same final answer as
-// one unlimited call: the result is the lexicographic minimum over all primitives, whatever the order.
+// UScene::intersectionPoint through the LBVH, one ray per lane. Returns the lexicographically smallest
+// (d, object, face) (object -1: no hit). while-while form: every lane of the wave descends until it holds a leaf
+// (or is done), then the fp64 primitive tests of all lanes run together. (The kernels that trace the rays of
+// large scenes walk the same tree with lanes refilled from a queue: wavefront_split.h.)
 template <bool EXACT = false>
-DEV bool closestHitBvhBudget(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc, uint32_t budget, Closest& best) {
-    if (S.num_prims == 0) return true;
+DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc) {
+    Closest best;
+    best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
+    if (S.num_prims == 0) return best;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
     const RayF q = makeRayF(r);
     float tmax = floatUp(best.d);
     st.sp = 0;
     int32_t node = 0;
-    uint32_t steps = 0;
     for (;;) {
-        while (node >= 0 && node != kTraversalDone) {
-            if (steps++ >= budget) return false;
-            node = descendIn<EXACT>(S, node, q, tmax, st, tc);
-        }
+        while (node >= 0 && node != kTraversalDone) node = descendIn<EXACT>(S, node, q, tmax, st, tc);
         if (node == kTraversalDone) break;
-        if (steps++ >= budget) return false;
         if (tc) { tc->prims++; countWaveStep(tc->wave_prims); }
         testPrimClosest(S, r, S.prims[~node], c, best);
         tmax = floatUp(best.d);
         node = st.sp ? st.pop() : kTraversalDone;
     }
-    return true;
-}
-template <bool EXACT = false>
-DEV Closest closestHitBvh(const DScene& S, const Ray& r, Stack& st, TraceCounters* tc) {
-    Closest best;
-    best.d = __builtin_inf(); best.u = 0; best.v = 0; best.object = -1; best.face = 0;
-    closestHitBvhBudget<EXACT>(S, r, st, tc, 0xffffffffu, best);
     return best;
 }
 
-// UScene::visibility through the LBVH with a budget of traversal steps (node visits + primitive
-// tests). A wave walks the tree until its slowest ray is done, and in a large scene a few rays need
-// ten times the steps of the rest: a caller that gives every ray a modest budget first and runs
-// the rays that exceeded it again, together, keeps far more lanes busy in both rounds. The answer
-// does not depend on the order the tree is walked in, so a second run from the root is exact.
-enum { kBlocked = 0, kVisible = 1, kOutOfBudget = 2 };
+// UScene::visibility through the LBVH: true when nothing blocks p0 -> p1 (the ray uscene.cpp:21-27 builds).
 template <bool EXACT = false>
-DEV int visibleBvhBudget(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc, uint32_t budget) {
+DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc) {
     double dist = length(p1 - p0);
     Ray r;
     r.o = p0;
     r.d = (p1 - p0) / dist;
-    if (S.num_prims == 0) return kVisible;
+    if (S.num_prims == 0) return true;
     LocalCache c;
     c.object = -1; c.gate_object = -1; c.gate_ok = false;
     const RayF q = makeRayF(r);
     const float tmax = floatUp(dist);
     st.sp = 0;
     int32_t node = 0;
-    uint32_t steps = 0;
     for (;;) {
-        while (node >= 0 && node != kTraversalDone) {
-            if (steps++ >= budget) return kOutOfBudget;
-            node = descendIn<EXACT>(S, node, q, tmax, st, tc);
-        }
+        while (node >= 0 && node != kTraversalDone) node = descendIn<EXACT>(S, node, q, tmax, st, tc);
         if (node == kTraversalDone) break;
-        if (steps++ >= budget) return kOutOfBudget;
         if (tc) { tc->prims++; countWaveStep(tc->wave_prims); }
-        if (testPrimBlocks(S, r, S.prims[~node], c, dist)) return kBlocked;
+        if (testPrimBlocks(S, r, S.prims[~node], c, dist)) return false;
         node = st.sp ? st.pop() : kTraversalDone;
     }
-    return kVisible;
-}
-
-// UScene::visibility through the LBVH: true when nothing blocks p0 -> p1.
-template <bool EXACT = false>
-DEV bool visibleBvh(const DScene& S, d3 p0, d3 p1, Stack& st, TraceCounters* tc) {
-    return visibleBvhBudget<EXACT>(S, p0, p1, st, tc, 0xffffffffu) == kVisible;
+    return true;
 }
 
 // ---- linear-scan accelerator: the reference's own loops, for cross-checking the tree --------------

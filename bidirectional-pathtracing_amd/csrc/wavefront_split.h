@@ -18,10 +18,11 @@
 
 namespace ub {
 
-// Waves per SIMD the ray-tracing kernels are compiled for (register budget = 512 / this; 1 = whatever the
-// compiler needs, which comes to 4). Measured on the 2 M-triangle scene with the persistent-wave kernels below:
-// 4 waves (128 registers, nothing spilled) 218 Mpaths/s, 5 waves (96 registers, 12..32 spilled inside the loop) 178,
-// 3 waves 210.
+// Waves per SIMD the ray-tracing kernels are compiled for (a MINIMUM: it caps the registers at 512 / this; 1 = whatever
+// the compiler needs). Measured on the 2 M-triangle scene with the persistent-wave kernels below: 4 waves (128
+// registers, nothing spilled) 218 Mpaths/s, 5 waves (96 registers, 12..34 spilled inside the loop) 178. Fewer resident
+// waves are slower (grid of 3 / 2 workgroups per CU instead of 4: 231 / 225 against 239), so occupancy does pay; it is
+// the fp64 state of a ray that caps it at 4.
 #ifndef UBDPT_TRACE_WAVES
 #define UBDPT_TRACE_WAVES 1
 #endif

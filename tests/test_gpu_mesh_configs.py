@@ -53,6 +53,12 @@ def test_full_size_render_properties(name, passes):
     assert (box.sum(axis=2) > 0).mean() > (0.95 if passes >= 4 else 0.9)  # two passes leave more of the dark corners unlit
     assert s["pixel_samples"] == W * H * passes
     assert 0 < max(k["max_stack_entries"] for k in s["kernels"]) <= 64
+    # traversal work per ray: a ray of these scenes meets about 1.4 primitives and 9 to 12 nodes. The walls are thin
+    # leaves in nodes that span the room; if their quantised boxes were taken as they come, every ray starting or ending
+    # on a wall would test the wall's triangles (2.3 primitive tests per ray)
+    rays = s["closest_hit_rays"] + s["shadow_rays"]
+    print(f"{name}: {s['prims_tested'] / rays:.2f} primitive tests and {s['bvh_nodes_visited'] / rays:.2f} node visits per ray")
+    assert s["prims_tested"] / rays < 1.8 and s["bvh_nodes_visited"] / rays < 14
     small = reduced(params, 20)
     orc = oracle_py.Oracle(scene, small, 32).set_accel(1)
     n_ref = 16
