@@ -1049,5 +1049,6 @@ extern "C" void ubdpt_debug_wave_times(unsigned long long* out) {
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ub::g_wave_times), sizeof(unsigned long long) * 16 * 12);
     (void)hipMemcpyFromSymbol(out + 16 * 12, HIP_SYMBOL(ub::g_wave_phase), sizeof(unsigned long long) * 8);
+    (void)hipMemcpyFromSymbol(out + 16 * 12 + 8, HIP_SYMBOL(ub::g_wave_lanes), sizeof(unsigned long long) * 4);
 }
 #endif

@@ -157,7 +157,12 @@ struct RayF {
 DEV RayF makeRayF(const Ray& r) {
     RayF q;
     q.ox = (float)r.o.x; q.oy = (float)r.o.y; q.oz = (float)r.o.z;
-    q.ix = 1.0f / (float)r.d.x; q.iy = 1.0f / (float)r.d.y; q.iz = 1.0f / (float)r.d.z;
+    // 1 / direction, limited to +-2^64: a ray parallel to a slab gets entry and exit parameters of +-huge or 0 (origin
+    // on the plane) exactly as an infinite reciprocal would give, never a NaN from 0 * inf, and every product stays finite
+    const float big = 18446744073709551616.0f;
+    q.ix = fminf(fmaxf(1.0f / (float)r.d.x, -big), big);
+    q.iy = fminf(fmaxf(1.0f / (float)r.d.y, -big), big);
+    q.iz = fminf(fmaxf(1.0f / (float)r.d.z, -big), big);
     q.pad = fmaxf(fabsf(q.ox), fmaxf(fabsf(q.oy), fabsf(q.oz))) * 2.384185791015625e-07f;  // 2^-22
     return q;
 }
@@ -232,21 +237,56 @@ DEV int32_t sortAndPush(float (&t)[kNodeWidth], int32_t (&c)[kNodeWidth], Stack&
     if (t[0] < inf) return c[0];
     return st.sp ? st.pop() : kTraversalDone;
 }
+// Slab tests of the children of a quantised node without decoding their boxes. Along axis a a child plane sits at
+// origin + byte * step; its ray parameter is computed as fma(byte, step, base) * (1 / d), where base =
+// (origin - o) -+ pad is formed once per node. Which plane a ray enters a slab through is known from the sign of its
+// direction, so the near and far planes are picked per NODE (the bytes of all children for one plane are one word)
+// and a child costs 6 conversions, 6 fused multiply-adds, 6 multiplications, a max3 and a min3.
+// Conservative: against the real-number plane origin + byte * step (which the builder holds within half an ulp of
+// the exact box, bvh.hip) the position fma(...) is off by the roundings of origin - o, of base and of the fma
+// itself: at most 3 * 2^-24 (M + |o|) for a scene of magnitude M; the M part, like the rounding of the ray itself
+// (2^-24 (2|o| + M), above), is inside the 2^-20 M every box was padded with at build time, the |o| part inside the
+// per-ray pad, which is doubled here to 2^-21 |o|; the product with 1 / d and its rounding are covered by the 2^-21
+// relative widening of the interval, as in slabF.
 DEV int32_t descendNode(const BvhNode& nd, const RayF& q, float tmax, Stack& st, TraceCounters* tc) {
     if (tc) { tc->nodes++; countWaveStep(tc->wave_nodes); }
     const float inf = __builtin_inff();
+    const float kWiden = 4.76837158203125e-07f;  // 2^-21
+    const float pad2 = q.pad + q.pad;
+    const float o[3] = {q.ox, q.oy, q.oz}, iv[3] = {q.ix, q.iy, q.iz};
+    float step[3], nbase[3], fbase[3];
+    uint32_t qn[3][kNodeQWords], qf[3][kNodeQWords];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        step[a] = nodeStep(nd.exps, a);
+        const float dmo = nd.origin[a] - o[a];
+        const float lb = dmo - pad2, hb = dmo + pad2;
+        const bool neg = iv[a] < 0.0f;
+        nbase[a] = neg ? hb : lb;
+        fbase[a] = neg ? lb : hb;
+#pragma unroll
+        for (int w = 0; w < kNodeQWords; w++) {
+            qn[a][w] = neg ? nd.q[3 + a][w] : nd.q[a][w];
+            qf[a][w] = neg ? nd.q[a][w] : nd.q[3 + a][w];
+        }
+    }
     float t[kNodeWidth];
     int32_t c[kNodeWidth];
-    const float sx = nodeStep(nd.exps, 0), sy = nodeStep(nd.exps, 1), sz = nodeStep(nd.exps, 2);
 #pragma unroll
     for (int k = 0; k < kNodeWidth; k++) {
         c[k] = nd.child[k];
         const int w = k >> 2, sh = 8 * (k & 3);
-        const float lo[3] = {nodeCoord(nd.origin[0], (nd.q[0][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[1][w] >> sh) & 0xffu, sy),
-                             nodeCoord(nd.origin[2], (nd.q[2][w] >> sh) & 0xffu, sz)};
-        const float hi[3] = {nodeCoord(nd.origin[0], (nd.q[3][w] >> sh) & 0xffu, sx), nodeCoord(nd.origin[1], (nd.q[4][w] >> sh) & 0xffu, sy),
-                             nodeCoord(nd.origin[2], (nd.q[5][w] >> sh) & 0xffu, sz)};
-        if (!(c[k] != kEmptyChild && slabF(lo, hi, q, tmax, t[k]))) t[k] = inf;
+        float tn = -inf, tf = inf;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float xn = __builtin_fmaf((float)((qn[a][w] >> sh) & 0xffu), step[a], nbase[a]);
+            const float xf = __builtin_fmaf((float)((qf[a][w] >> sh) & 0xffu), step[a], fbase[a]);
+            tn = fmaxf(tn, xn * iv[a]);
+            tf = fminf(tf, xf * iv[a]);
+        }
+        tn = tn - fabsf(tn) * kWiden;
+        tf = tf + fabsf(tf) * kWiden;
+        t[k] = (c[k] != kEmptyChild && tn <= tf && tf >= 0.0f && tn <= tmax) ? tn : inf;
     }
     return sortAndPush(t, c, st, tc);
 }

@@ -78,7 +78,13 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // average (its longest ray). Measured and not kept: requesting the next node or primitive at the end of an
 // iteration and using it in the next (one wait per iteration instead of two, but one step per lane and iteration
 // and 12 more live registers): 212 against 239 Mpaths/s; five waves per SIMD: 12 to 34 registers spilled; testing
-// leaves at once when the queue has run dry instead of waiting for a batch: no difference (three alternating runs).
+// leaves at once when the queue has run dry instead of waiting for a batch: no difference (three alternating runs);
+// a ring of 64 rays per wave in LDS, filled ahead by LDS-DMA (global_load_lds from the carry records), out of which a
+// lane that finishes takes its next ray in the same iteration: lanes per node step 37 -> 43 of 64, iterations -14 %,
+// and every iteration that much longer: 247 against 251 Mpaths/s. The loop is not paced by its iteration count:
+// eight-wide nodes (-40 % node steps), the ring (-14 % iterations) and cheaper slab tests (-150 instructions per node
+// step, +3.5 %) all leave the time of a launch nearly where it was; half of it is the fp64 leaf phase (primitive fetch,
+// triangle test, bounding-sphere gate), which none of them touches.
 #ifndef UBDPT_RAY_CHUNK
 #define UBDPT_RAY_CHUNK 256
 #endif
@@ -146,6 +152,8 @@ __device__ unsigned long long g_wave_times[16][12];
 // phases of the loop, summed over waves (ticks): [0] arrivals, [1] feeding, [2] node fetch wait, [3] node step arithmetic,
 // [4] primitive fetch wait, [5] primitive arithmetic
 __device__ unsigned long long g_wave_phase[8];
+// lanes by state at the node step, summed over iterations and waves: idle, waiting for their ray, at an inner node, at a leaf
+__device__ unsigned long long g_wave_lanes[4];
 #define WT_STAMP(k) { const unsigned long long n_ = wall_clock64(); wt_phase[k] += n_ - wt_last; wt_last = n_; }
 #else
 #define WT_STAMP(k)
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
 #ifdef UBDPT_WAVE_TIMES
     const unsigned long long wt_start = wall_clock64();
     unsigned long long wt_drained = 0, wt_iters = 0, wt_steps = 0, wt_claim = 0, wt_leaf = 0;
-    unsigned long long wt_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = wt_start;
+    unsigned long long wt_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt_last = wt_start, wt_lanes[4] = {0, 0, 0, 0};
     if (gid == 0 && !STATS) { atomicAdd(&g_wave_times[depth][8], 1ULL); atomicAdd(&g_wave_times[depth][9], (unsigned long long)total); }
 #endif
     for (;;) {
@@ -258,6 +266,10 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
         if (act_m == 0) continue;
 #ifdef UBDPT_WAVE_TIMES
         wt_steps++;
+        wt_lanes[0] += __popcll(__ballot(state == ST_IDLE));
+        wt_lanes[1] += __popcll(__ballot(state == ST_ID || state == ST_RAY));
+        wt_lanes[2] += __popcll(__ballot(state == ST_ACTIVE && node >= 0));
+        wt_lanes[3] += __popcll(__ballot(state == ST_ACTIVE && node < 0));
 #endif
         // (3) one node step for every lane that stands at an inner node
 #ifdef UBDPT_WAVE_TIMES
@@ -305,6 +317,9 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
                         (wt_pr.face == kSphereFace || meshGate(S, (int32_t)wt_pr.object, c))) {
                         best.d = wt_d; best.u = wt_u; best.v = wt_v; best.object = (int32_t)wt_pr.object; best.face = wt_pr.face;
                     }
+                }
+                WT_STAMP(4)  // (measurement of the gate alone: its time is added to the primitive fetch column)
+                if (wt_on) {
                     tmax = floatUp(best.d);
                     node = st.sp ? st.pop() : kTraversalDone;
                     if (node == kTraversalDone) { storeHit(A, id, best); state = ST_IDLE; }
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(kBlock, traceWaves(LDS_LEVEL)) void k_wf_trace(Rend
             atomicAdd(&g[7], wt_claim);
             atomicAdd(&g[10], wt_leaf);
             for (int k = 0; k < 8; k++) atomicAdd(&g_wave_phase[k], wt_phase[k]);
+            for (int k = 0; k < 4; k++) atomicAdd(&g_wave_lanes[k], wt_lanes[k]);
         } else
             atomicAdd(&g[5], 1ULL);
     }

@@ -14,7 +14,7 @@ d = json.loads(buf.getvalue().strip().splitlines()[-1])
 from importlib import import_module
 capi = import_module("bidirectional-pathtracing_amd.capi")
 lib = ctypes.CDLL(capi.LIB_PATH)
-out = (ctypes.c_ulonglong * (16 * 12 + 8))()
+out = (ctypes.c_ulonglong * (16 * 12 + 12))()
 lib.ubdpt_debug_wave_times(out)
 print(os.path.basename(capi.LIB_PATH), "%.1f Mpaths/s" % d["value"], "trace ms/launch %.3f" % d["kernels"]["k_wf_trace"]["ms_per_launch"],
       "nodes/ray %.2f" % d["work_per_pixel_sample"]["nodes_per_ray"])
@@ -30,5 +30,8 @@ ph = [out[16 * 12 + k] for k in range(8)]
 tot = float(sum(ph)) or 1.0
 print("  loop phases: arrivals %.1f %%, feeding %.1f %%, node fetch wait %.1f %%, node arithmetic %.1f %%, primitive fetch wait %.1f %%, local ray %.1f %%, primitive test %.1f %%, gate / pop / store %.1f %%"
       % tuple(100.0 * x / tot for x in ph))
+ln = [out[16 * 12 + 8 + k] for k in range(4)]
+tl = float(sum(ln)) or 1.0
+print("  lanes at the node step: idle %.1f %%, waiting for their ray %.1f %%, at an inner node %.1f %%, at a leaf %.1f %%" % tuple(100.0 * x / tl for x in ln))
 PY
 done
