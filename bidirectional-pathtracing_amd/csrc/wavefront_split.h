@@ -84,7 +84,10 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 // and every iteration that much longer: 247 against 251 Mpaths/s. The loop is not paced by its iteration count:
 // eight-wide nodes (-40 % node steps), the ring (-14 % iterations) and cheaper slab tests (-150 instructions per node
 // step, +3.5 %) all leave the time of a launch nearly where it was; half of it is the fp64 leaf phase (primitive fetch,
-// triangle test, bounding-sphere gate), which none of them touches.
+// triangle test, bounding-sphere gate), which none of them touches. Copying a leaf's primitive record into a per-lane
+// LDS slot by LDS-DMA when the lane arrives at the leaf and testing it one iteration later (no wait for the primitive):
+// this kernel 1.39 -> 1.30 ms per launch, but with 40 KB of LDS per workgroup the kernels of the other batch lane
+// slowed down by more: 248 against 252 Mpaths/s.
 #ifndef UBDPT_RAY_CHUNK
 #define UBDPT_RAY_CHUNK 256
 #endif
