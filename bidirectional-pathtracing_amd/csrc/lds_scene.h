@@ -12,7 +12,10 @@
 namespace ub {
 
 constexpr uint32_t kLdsObjectsShade = 64;  // shading kernels hold 2 workgroups per CU
-constexpr uint32_t kLdsObjectsTrace = 32;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
+#ifndef UBDPT_LDS_OBJECTS_TRACE
+#define UBDPT_LDS_OBJECTS_TRACE 32
+#endif
+constexpr uint32_t kLdsObjectsTrace = UBDPT_LDS_OBJECTS_TRACE;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
 constexpr uint32_t kLdsTreePrims = kExactTreePrims;
 
 // Every thread of the workgroup must call this; the returned pointer replaces DScene::objects.

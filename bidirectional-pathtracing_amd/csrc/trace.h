@@ -18,7 +18,10 @@ namespace ub {
 
 #define DEV __device__ __forceinline__
 
-constexpr int kLdsStack = 12;      // stack entries per lane kept in LDS
+#ifndef UBDPT_LDS_STACK
+#define UBDPT_LDS_STACK 12
+#endif
+constexpr int kLdsStack = UBDPT_LDS_STACK;  // stack entries per lane kept in LDS
 constexpr int kOverflowStack = 96; // further entries per lane in HBM
 
 struct Ray {
