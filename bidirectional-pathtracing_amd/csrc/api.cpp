@@ -552,7 +552,13 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix * (1 + c->pass_slots), c->stream));
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
-        c->pair_capacity = c->cap_paths * 24;
+        // pair / ray / visible-pair queues: 24 entries per pixel-sample (a box scene averages 6 to 10); pixel-samples
+        // beyond the queue's end are finished by k_pair_overflow. UBDPT_PAIR_QUEUE_PER_PATH shrinks it for tests of that path.
+        {
+            const char* e = getenv("UBDPT_PAIR_QUEUE_PER_PATH");
+            const unsigned long long per_path_entries = e && atoi(e) > 0 ? (unsigned long long)atoi(e) : 24ull;
+            c->pair_capacity = c->cap_paths * std::min(per_path_entries, 24ull);
+        }
         c->lanes.resize(nstreams);
         for (auto& b : c->lanes) {
             ck(hipStreamCreate(&b.stream));
@@ -567,7 +573,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             ck(hipMalloc((void**)&b.d_wf_hit, sizeof(double) * kHitDoubles * n2));
             ck(hipMalloc((void**)&b.d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
             ck(hipMalloc((void**)&b.d_vis_count, sizeof(uint32_t)));
-            ck(hipMalloc((void**)&b.d_ray_count, 2 * sizeof(uint32_t)));
+            ck(hipMalloc((void**)&b.d_ray_count, 3 * sizeof(uint32_t)));
             if (c->opt.pipeline == 0) {
                 ck(hipMalloc((void**)&b.d_rays, sizeof(double) * kRayDoubles * c->pair_capacity));
                 ck(hipMalloc((void**)&b.d_ray_flag, c->pair_capacity));
@@ -728,10 +734,8 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
             run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
             HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
             HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
-            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 2 * sizeof(uint32_t), sm));
-            A.ovf_stride = A.E.n;  // the enumeration runs one lane per pixel-sample (its slow path traces rays)
-            run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, stats, sm); });
-            A.ovf_stride = pstride;
+            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 3 * sizeof(uint32_t), sm));
+            run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, pblocks, stats, sm); });
             if (sceneLdsLevel(A.S) == 2) {
                 run(K_RAYS_VISIBLE, units, [&] { launchPairVisibleLds(A, pblocks, stats, sm); });
             } else {

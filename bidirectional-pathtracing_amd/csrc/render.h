@@ -32,7 +32,7 @@ struct RenderArgs {
     uint32_t* vis_count;
     double* rays;            // shadow-ray queue, kRayDoubles per ray: origin, direction, length
     uint64_t* ray_pairs;     // the pair each ray of the queue belongs to
-    uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at
+    uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at; ray_count[2] = pixel-samples k_pair_enum could not queue
     uint32_t* ray_head;
     uint8_t* ray_flag;       // one per ray: 1 = nothing blocks it
     uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
@@ -61,7 +61,7 @@ constexpr int kNumCounters = 16;
 void launchEye(const RenderArgs& A, bool stats, hipStream_t s);
 void launchLight(const RenderArgs& A, bool stats, hipStream_t s);
 void launchConnect(const RenderArgs& A, bool stats, hipStream_t s);
-void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s);
+void launchPairEnum(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s);
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,

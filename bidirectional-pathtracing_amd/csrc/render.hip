@@ -594,9 +594,11 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
 // One lane per pixel-sample: appends its connectable (s,t) pairs to the pair queue. The specular
 // bits of the first kMaskedVertices vertices travel in the subpath's count word, so the common case
 // reads two words per pixel-sample; queue space is reserved with one atomic per workgroup.
+// A pixel-sample whose pairs no longer fit the queue goes to a list instead (A.wf_trace_q, free once the subpaths
+// are complete; its length is A.ray_count[2]) and k_pair_overflow evaluates its pairs one by one: same result,
+// and this kernel stays small (the slow path inside it cost it three quarters of its occupancy).
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
-    __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x;
@@ -640,11 +642,30 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
             }
         }
     } else {
-        // queue full: this lane evaluates its own pairs (slow path, same result); the part of its
-        // reservation that lies inside the queue is filled with skip records (s == 0)
+        // queue full: the part of this lane's reservation that lies inside the queue is filled with skip records
+        // (s == 0), and the pixel-sample is listed for k_pair_overflow
         for (unsigned long long j = pos; j < pos + cnt && j < A.pair_capacity; j++) A.pairs[j] = 0;
-        Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid, A.ovf_cap);
-        Tally ty;
+        A.wf_trace_q[atomicAdd(&A.ray_count[2], 1u)] = (uint32_t)gid;
+    }
+}
+
+// The pixel-samples k_pair_enum could not queue: every lane runs the connection loop of its pixel-sample (shadow ray
+// included), the reference's loop structure. Launched after every k_pair_enum; the list is almost always empty.
+template <bool STATS>
+__global__ __launch_bounds__(kBlock) void k_pair_overflow(RenderArgs A) {
+    __shared__ int32_t lds_stack[kLdsStack * kBlock];
+    const uint64_t gid0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
+    const uint32_t total = A.ray_count[2];
+    if (total == 0) return;
+    const PathStore& E = A.E;
+    const PathStore& L = A.L;
+    Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid0, A.ovf_cap);
+    Tally ty;
+    for (uint64_t j = gid0; j < total; j += nthreads) {
+        const uint64_t gid = A.wf_trace_q[j];
+        const uint32_t mE = E.meta(gid), mL = L.meta(gid);
+        const uint32_t nE = mE & 0xff, nL = mL & 0xff;
         for (uint32_t s = 1; s <= nL; s++) {
             if (!L.connectable(mL, s - 1, gid)) continue;
             for (uint32_t t = 1; t <= nE; t++) {
@@ -652,9 +673,9 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
                 connectPair<STATS>(A, gid, s, t, st, ty);
             }
         }
-        if (STATS) flushTally(ty, A.counters, 0, 0);
-        if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
     }
+    if (STATS) flushTally(ty, A.counters, 0, 0);
+    if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);
 }
 
 }  // namespace ub
@@ -900,9 +921,13 @@ void launchWfGen(const RenderArgs& A, bool stats, hipStream_t s) {
 void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool stats, hipStream_t s) {
     UBDPT_LAUNCH_TRACE(k_wf_tail, A, depth);
 }
-void launchPairEnum(const RenderArgs& A, bool stats, hipStream_t s) {
+// `blocks`: grid of the kernel that finishes the pixel-samples the queue had no room for (its lanes index the
+// traversal stacks' overflow buffer, which the caller sized for that grid)
+void launchPairEnum(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_enum<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
+    if (stats) hipLaunchKernelGGL(k_pair_overflow<true>, dim3(blocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_overflow<false>, dim3(blocks), dim3(kBlock), 0, s, A);
 }
 // picks the instantiation (counting or not, object table in LDS or not) of a kernel template K<bool, uint32_t>
 #define UBDPT_LAUNCH_LDS(K, CAP, ...)                                                                          \

@@ -216,6 +216,30 @@ def test_image_matches_oracle_path_by_path(oracle_mod, name, passes, accel, pipe
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["C2", "mesh6k"])
+def test_pair_queue_overflow_gives_the_same_image(oracle_mod, name, monkeypatch):
+    """The pair queue holds 24 connections per pixel-sample of a batch; pixel-samples that no longer fit are
+    finished by k_pair_overflow with the reference's loop structure. With room for 2 per pixel-sample most of the
+    batch takes that path: the image and the counters must still match the oracle path by path."""
+    w = h = 48
+    passes = 3
+    monkeypatch.setenv("UBDPT_PAIR_QUEUE_PER_PATH", "2")
+    scene, ctx, orc = make_pair(oracle_mod, name, w=w, h=h, stats=1)
+    monkeypatch.delenv("UBDPT_PAIR_QUEUE_PER_PATH")
+    st, done = ctx.render_passes(0, passes, SEED)
+    assert st == capi.SUCCESS and done == passes
+    got = ctx.read_sum()
+    s = ctx.stats()
+    ctx.close()
+    ref, cn = orc.render_passes(0, passes, SEED, num_threads=4, counters=True)
+    bad, rm = image_agreement(got, ref, passes)
+    assert bad <= BAD_PIXELS_MAX and rm <= 2e-3, (bad, rm)
+    for k, tol in (("connections", 5e-3), ("splats", 5e-3)):
+        assert abs(s[k] - cn[k]) <= tol * cn[k] + 2, (k, s[k], cn[k])
+    # more connections than the shrunken queue can hold were evaluated: the overflow path did run
+    assert s["connections"] > 2 * w * h * passes
+
+
 @pytest.mark.parametrize("n_spheres", [20, 30, 70])
 def test_image_parity_across_scene_sizes_that_change_the_memory_placement(oracle_mod, n_spheres):
     """The kernels keep small scenes in LDS: tree, primitives and objects up to 48 primitives / 32 objects,
