@@ -546,6 +546,71 @@ def test_large_mesh_lbvh_equals_linear_scan(n_tris, n_rays):
     assert np.array_equal(v0, v1) and 0 < v1.sum() < n_rays
 
 
+@pytest.mark.parametrize("shift", [(0.0, 0.0, 0.0), (300.0, -200.0, 500.0), (5000.0, 3000.0, -4000.0)])
+def test_tree_never_loses_a_hit_on_edges_corners_and_far_from_the_origin(shift):
+    """The tree is walked in fp32 through quantised boxes; what keeps it exact is that a box is never rejected for a
+    ray the fp64 primitive test accepts. The rays that probe this are the ones through the rim of a box: aimed at
+    corners and edge points of triangles, from near and far, with axis-parallel directions among them, and the
+    same with the whole scene moved far from the origin, where fp32 coordinates are coarsest. Hit identity and
+    every hit field must equal the device's linear scan bit for bit; visibility likewise."""
+    n_tris, n_rays = 20_000, 1 << 15
+    scene = scenes.mesh_scene(n_tris, seed=3, ratio=1.0)
+    sh = np.asarray(shift)
+    for i in range(scene.n_objects):
+        for k in range(3):
+            scene.objects[i].W[12 + k] += sh[k]
+    cam = scene.desc.camera
+    for k in range(3):
+        cam.pos[k] += sh[k]; cam.look_at[k] += sh[k]
+    scene.desc.camera = cam
+    # world-space corners of random faces
+    rng = np.random.default_rng(11)
+    face_obj = np.zeros(scene.num_faces, np.int64)
+    Ws = []
+    for i in range(scene.n_objects):
+        o = scene.objects[i]
+        Ws.append(np.array(list(o.W)).reshape(4, 4).T)
+        if o.kind == capi.MODEL_MESH:
+            face_obj[o.first_face:o.first_face + o.num_faces] = i
+    f = rng.integers(0, scene.num_faces, n_rays)
+    P = scene.vertices["pos"].reshape(-1, 3, 3)[f].astype(np.float64)           # [n][corner][xyz], object-local
+    Wf = np.stack([Ws[i] for i in face_obj[f]])
+    Pw = np.einsum("nij,ncj->nci", Wf[:, :3, :3], P) + Wf[:, None, :3, 3]
+    bary = rng.dirichlet((1, 1, 1), n_rays)
+    kind = rng.integers(0, 3, n_rays)
+    bary[kind == 0] = np.eye(3)[rng.integers(0, 3, (kind == 0).sum())]            # a corner
+    e = kind == 1                                                                  # a point of an edge
+    bary[e, rng.integers(0, 3, e.sum())] = 0.0
+    bary[e] /= bary[e].sum(axis=1, keepdims=True)
+    target = np.einsum("nc,nci->ni", bary, Pw)
+    d = rng.normal(size=(n_rays, 3))
+    axis = rng.integers(0, 4, n_rays)                                              # a quarter of the rays run along an axis
+    for a in range(3):
+        d[axis == a] = np.eye(3)[a] * rng.choice([-1.0, 1.0], (axis == a).sum())[:, None]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    dist = rng.choice([1e-3, 0.05, 0.7, 3.0, 40.0], n_rays)
+    rays = np.zeros(n_rays, capi.RAY_DTYPE)
+    rays["origin"] = target - d * dist[:, None]
+    rays["dir"] = d
+    segs = np.zeros(n_rays, capi.SEGMENT_DTYPE)
+    segs["p0"] = rays["origin"]
+    segs["p1"] = target + d * rng.choice([-1e-4, 1e-4, 0.3], n_rays)[:, None]
+    res = []
+    for accel in (0, 1):
+        opt = capi.Options()
+        opt.accel = accel
+        with capi.Context(scene, scenes.make_params(32, 32), opt) as ctx:
+            res.append((ctx.intersect_batch(rays), ctx.visibility_batch(segs)))
+    (h0, v0), (h1, v1) = res
+    assert np.array_equal(h0["hit"], h1["hit"]) and np.array_equal(h0["object"], h1["object"])
+    assert np.array_equal(h0["face"], h1["face"])
+    m = h1["hit"] == 1
+    assert m.sum() > n_rays // 2
+    for fld in ("d", "pos", "Ng", "Ns", "Ts", "Bs", "tex_u", "tex_v"):
+        assert np.array_equal(h0[fld][m].view(np.uint64), h1[fld][m].view(np.uint64)), fld
+    assert np.array_equal(v0, v1) and 0 < v1.sum() < n_rays
+
+
 @pytest.mark.parametrize("name", ["C1", "C2"])
 def test_relmse_gate_against_independent_reference_seeds(oracle_mod, name):
     """The statistical gate for images: at equal spp the backend's image must be as close to an
