@@ -5,7 +5,7 @@ timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 rc=$?
 tail -3 gpurun_out/t_$tag.log
 [ $rc -ne 0 ] && exit $rc
-timeout -k 10 200 python3 bench.py "$@" > gpurun_out/b_$tag.json 2> gpurun_out/b_$tag.err || exit $?
+timeout -k 10 400 python3 bench.py "$@" > gpurun_out/b_$tag.json 2> gpurun_out/b_$tag.err || exit $?
 python3 - "$tag" <<'PY'
 import json,sys
 d=json.loads(open(f"gpurun_out/b_{sys.argv[1]}.json").read().strip().splitlines()[-1])
