@@ -926,8 +926,11 @@ void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool sta
 void launchPairEnum(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_enum<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
-    if (stats) hipLaunchKernelGGL(k_pair_overflow<true>, dim3(blocks), dim3(kBlock), 0, s, A);
-    else hipLaunchKernelGGL(k_pair_overflow<false>, dim3(blocks), dim3(kBlock), 0, s, A);
+    // one workgroup per CU at most: the list is almost always empty, and a workgroup of this kernel needs half a SIMD's
+    // registers to start at all
+    const unsigned oblocks = blocks < 256u ? blocks : 256u;
+    if (stats) hipLaunchKernelGGL(k_pair_overflow<true>, dim3(oblocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_overflow<false>, dim3(oblocks), dim3(kBlock), 0, s, A);
 }
 // picks the instantiation (counting or not, object table in LDS or not) of a kernel template K<bool, uint32_t>
 #define UBDPT_LAUNCH_LDS(K, CAP, ...)                                                                          \
