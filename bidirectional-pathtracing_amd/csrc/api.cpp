@@ -542,7 +542,11 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             c->cap_paths = std::max<uint64_t>(4096, (c->opt.batch_pixel_samples + 255) / 256 * 256);
         }
         if (2 * c->cap_paths >= (1ull << 29) - 1) { st = UBDPT_INVALID_ARG; break; }
-        c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth) : 8;
+        // bounces run as wavefront launches before the per-lane tail kernel takes the survivors: every launch of the
+        // persistent trace kernel ends with the tail of its longest ray, which the last, thin bounces do not pay back
+        // on scenes in HBM (2 M triangles: depth 6 / 7 / 8 = 260 / 255 / 253 Mpaths/s); a scene in LDS prefers 8
+        c->wf_depth = c->opt.wavefront_depth ? std::min<uint32_t>(c->opt.wavefront_depth, kMaxWfDepth)
+                                             : (sceneLdsLevel(c->S) == 2 ? 8u : 6u);
         c->pass_slots = std::min<uint32_t>(c->opt.pass_slots, 64);
         c->ovf_cap = c->opt.traversal_stack_entries ? std::min<uint32_t>(c->opt.traversal_stack_entries, kLdsStack + kOverflowStack) : kLdsStack + kOverflowStack;
         for (int& f : c->slot_fence) f = -1;
