@@ -291,12 +291,16 @@ bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::
 }
 
 // binary PPM (P6, maxval 255) -> RGBA8888 rows, alpha 255
+// Netpbm images with 8-bit samples: P6 / P3 (colour, binary / text) and P5 / P2 (grey, binary / text), as RGBA8888
+// (what TextureImg keeps of a QImage, uapp/textureimg.cpp:19-33).
 bool loadPpm(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
     std::ifstream in(path, std::ios::binary);
     if (!in.is_open()) return false;
     std::string magic;
     in >> magic;
-    if (magic != "P6") return false;
+    if (magic != "P6" && magic != "P3" && magic != "P5" && magic != "P2") return false;
+    const bool text = magic == "P3" || magic == "P2";
+    const size_t channels = (magic == "P6" || magic == "P3") ? 3 : 1;
     auto nextInt = [&](long& v) {
         for (;;) {
             int c = in.peek();
@@ -308,14 +312,23 @@ bool loadPpm(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint
     };
     long W = 0, H = 0, maxv = 0;
     if (!nextInt(W) || !nextInt(H) || !nextInt(maxv) || W <= 0 || H <= 0 || maxv != 255) return false;
-    in.get();  // the single whitespace byte after maxval
-    std::vector<uint8_t> rgb((size_t)W * H * 3);
-    in.read(reinterpret_cast<char*>(rgb.data()), (std::streamsize)rgb.size());
-    if ((size_t)in.gcount() != rgb.size()) return false;
+    std::vector<uint8_t> samples((size_t)W * H * channels);
+    if (text) {
+        for (uint8_t& x : samples) {
+            long v = 0;
+            if (!nextInt(v) || v < 0 || v > 255) return false;
+            x = (uint8_t)v;
+        }
+    } else {
+        in.get();  // the single whitespace byte after maxval
+        in.read(reinterpret_cast<char*>(samples.data()), (std::streamsize)samples.size());
+        if ((size_t)in.gcount() != samples.size()) return false;
+    }
     w = (uint32_t)W; h = (uint32_t)H;
     rgba.resize((size_t)W * H * 4);
     for (size_t p = 0; p < (size_t)W * H; p++) {
-        rgba[4 * p] = rgb[3 * p]; rgba[4 * p + 1] = rgb[3 * p + 1]; rgba[4 * p + 2] = rgb[3 * p + 2]; rgba[4 * p + 3] = 255;
+        for (size_t k = 0; k < 3; k++) rgba[4 * p + k] = samples[channels * p + (channels == 3 ? k : 0)];
+        rgba[4 * p + 3] = 255;
     }
     return true;
 }

@@ -195,6 +195,28 @@ def test_obj_file_yields_one_object_per_model(tmp_path):
     assert np.isfinite(img).all() and img.sum() > 0
 
 
+def test_texture_file_formats(tmp_path):
+    """Binary and text, colour and grey Netpbm files give the same texels (grey replicated into three channels)."""
+    img = write_files(tmp_path)
+    H, W = img.shape[:2]
+    (tmp_path / "t3.ppm").write_text("P3\n# text form\n%d %d\n255\n" % (W, H) + " ".join(str(int(x)) for x in img.reshape(-1)) + "\n")
+    grey = img[..., 0]
+    with open(tmp_path / "t5.pgm", "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (W, H) + grey.tobytes())
+    (tmp_path / "t2.pgm").write_text("P2\n%d %d\n255\n" % (W, H) + "\n".join(" ".join(str(int(x)) for x in row) for row in grey) + "\n")
+    def texels(name):
+        (tmp_path / "s.xml").write_text(XML.replace("checker.ppm", name))
+        xs = hostapi.XmlScene(str(tmp_path / "s.xml"), str(tmp_path))
+        n = xs.desc.num_texel_bytes
+        return np.frombuffer(bytes(bytearray(xs.desc.texels[k] for k in range(n))), np.uint8).reshape(H, W, 4)
+    base = texels("checker.ppm")
+    assert np.array_equal(base[..., :3], img) and (base[..., 3] == 255).all()
+    assert np.array_equal(texels("t3.ppm"), base)
+    g5, g2 = texels("t5.pgm"), texels("t2.pgm")
+    assert np.array_equal(g5, g2)
+    assert all(np.array_equal(g5[..., k], grey) for k in range(3)) and (g5[..., 3] == 255).all()
+
+
 def test_loader_errors(tmp_path):
     write_files(tmp_path)
     with pytest.raises(RuntimeError, match="Failed to open scene file"):
