@@ -99,7 +99,7 @@ DEV uint32_t blockAppend(bool pred, uint32_t* counter, uint32_t* s_wave, uint32_
 #define UBDPT_REFILL_MIN 16
 #endif
 #ifndef UBDPT_LEAF_BATCH
-#define UBDPT_LEAF_BATCH 12
+#define UBDPT_LEAF_BATCH 20
 #endif
 #ifndef UBDPT_LEAF_WAIT
 #define UBDPT_LEAF_WAIT 3
