@@ -13,9 +13,11 @@ namespace ub {
 
 constexpr uint32_t kLdsObjectsShade = 64;  // shading kernels hold 2 workgroups per CU
 #ifndef UBDPT_LDS_OBJECTS_TRACE
-#define UBDPT_LDS_OBJECTS_TRACE 32
+#define UBDPT_LDS_OBJECTS_TRACE 16
 #endif
-constexpr uint32_t kLdsObjectsTrace = UBDPT_LDS_OBJECTS_TRACE;  // ray tracing kernels hold 4 and keep their traversal stacks in LDS as well
+// ray tracing kernels hold 4 workgroups per CU and keep their traversal stacks in LDS as well; with room for 32 objects
+// (15 KB) the box of 14 primitives rendered 2 to 3 % slower and the 2 M-triangle scene the same
+constexpr uint32_t kLdsObjectsTrace = UBDPT_LDS_OBJECTS_TRACE;
 constexpr uint32_t kLdsTreePrims = kExactTreePrims;
 
 // Every thread of the workgroup must call this; the returned pointer replaces DScene::objects.

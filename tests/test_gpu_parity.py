@@ -240,10 +240,10 @@ def test_pair_queue_overflow_gives_the_same_image(oracle_mod, name, monkeypatch)
     assert s["connections"] > 2 * w * h * passes
 
 
-@pytest.mark.parametrize("n_spheres", [20, 30, 70])
+@pytest.mark.parametrize("n_spheres", [6, 20, 30, 70])
 def test_image_parity_across_scene_sizes_that_change_the_memory_placement(oracle_mod, n_spheres):
-    """The kernels keep small scenes in LDS: tree, primitives and objects up to 48 primitives / 32 objects,
-    the object table alone up to 64 objects (shading), everything in HBM beyond. 26, 36 and 76 objects
+    """The kernels keep small scenes in LDS: tree, primitives and objects up to 48 primitives / 16 objects,
+    the object table alone up to 64 objects (shading), everything in HBM beyond. 12, 26 / 36 and 76 objects
     select the three placements; the image must match the oracle path by path in each."""
     w = h = 40
     passes = 2
