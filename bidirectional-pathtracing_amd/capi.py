@@ -107,6 +107,7 @@ EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
     "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
     "ubdpt_read_sum_device", "ubdpt_accumulate_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
+    "ubdpt_read_sum_slot_onto",
     "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
     "ubdpt_get_image_size", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
@@ -167,6 +168,7 @@ def load_library(path=None):
     lib.ubdpt_request_stop.argtypes = [vp]
     lib.ubdpt_render_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum_slot.argtypes = [vp, C.c_uint32, vp, C.c_int]
+    lib.ubdpt_read_sum_slot_onto.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
     lib.ubdpt_enqueue_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum.argtypes = [vp, vp, C.c_int]
     lib.ubdpt_read_sum_device.argtypes = [vp, vp]
@@ -261,6 +263,14 @@ class Context:
             out = np.zeros((self.height, self.width, 3), np.float64)
         assert out.dtype == np.float64 and out.flags.c_contiguous and out.shape == (self.height, self.width, 3)
         _check(self.lib.ubdpt_read_sum_slot(self.handle, slot, out.ctypes.data, 1 if add_into else 0), "ubdpt_read_sum_slot")
+        return out
+
+    def read_sum_slot_onto(self, slot, base, out, host_threads=1):
+        """out = base + per-pass buffer `slot` (base None: the pass itself; base may be out)."""
+        for a in (base, out):
+            assert a is None or (a.dtype == np.float64 and a.flags.c_contiguous and a.shape == (self.height, self.width, 3))
+        _check(self.lib.ubdpt_read_sum_slot_onto(self.handle, slot, None if base is None else base.ctypes.data, out.ctypes.data,
+                                                 host_threads), "ubdpt_read_sum_slot_onto")
         return out
 
     def enqueue_passes(self, first_pass, n_passes, seed, pass_stride=1):

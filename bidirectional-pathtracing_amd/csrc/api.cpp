@@ -16,6 +16,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "render.h"
@@ -844,7 +845,28 @@ int ubdpt_accumulate_sum_device(ubdpt_context* c, double* device_rgb) {
 }
 
 // buffer 0 is the sum buffer, buffer 1 + k the per-pass buffer k
-static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add_into) {
+// out[i] = base[i] + add[i] over n doubles on up to `threads` host threads (contiguous ranges; one thread below a
+// million doubles, where starting threads costs more than the loop). base may be out.
+static void addOnto(const double* base, const double* add, double* out, uint64_t n, unsigned threads) {
+    auto body = [=](uint64_t a, uint64_t b) {
+        for (uint64_t i = a; i < b; i++) out[i] = base[i] + add[i];
+    };
+    threads = std::max(1u, std::min(threads, 16u));
+    if (n < (1ull << 20) || threads == 1) { body(0, n); return; }
+    uint64_t per = (n + threads - 1) / threads;
+    per = (per + 511) & ~511ull;  // whole pages per thread
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; t++) {
+        const uint64_t a = (uint64_t)t * per;
+        if (a >= n) break;
+        pool.emplace_back(body, a, std::min(n, a + per));
+    }
+    body(0, std::min(n, per));
+    for (auto& th : pool) th.join();
+}
+
+// out = the buffer (base == nullptr) or out = base + the buffer (base may be out)
+static int readSumBuffer(ubdpt_context* c, uint32_t buffer, const double* base, double* out, unsigned threads) {
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     const int fence = (buffer >= 1 && c->work_pending) ? c->slot_fence[buffer - 1] : -1;
@@ -857,8 +879,8 @@ static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add
     }
     launchInterleave(c->d_fb + (uint64_t)buffer * 3 * c->npix, c->npix, c->d_staging, c->stream);
     HIPCK(c, hipGetLastError());
-    if (!add_into) {
-        HIPCK(c, hipMemcpyAsync(rgb, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
+    if (!base) {
+        HIPCK(c, hipMemcpyAsync(out, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
     } else {
         // the reference-shaped renderPass comes here once per pass: a pinned staging buffer kept for the life of the
@@ -866,20 +888,24 @@ static int readSumBuffer(ubdpt_context* c, uint32_t buffer, double* rgb, int add
         if (!c->h_staging) HIPCK(c, hipHostMalloc((void**)&c->h_staging, sizeof(double) * 3 * c->npix, hipHostMallocDefault));
         HIPCK(c, hipMemcpyAsync(c->h_staging, c->d_staging, sizeof(double) * 3 * c->npix, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
-        const double* tmp = c->h_staging;
-        for (uint64_t i = 0; i < 3 * c->npix; i++) rgb[i] += tmp[i];
+        addOnto(base, c->h_staging, out, 3 * c->npix, threads);
     }
     return UBDPT_SUCCESS;
 }
 
 int ubdpt_read_sum(ubdpt_context* c, double* rgb, int add_into) {
     if (!c || !rgb) return UBDPT_INVALID_ARG;
-    return readSumBuffer(c, 0, rgb, add_into);
+    return readSumBuffer(c, 0, add_into ? rgb : nullptr, rgb, 1);
 }
 
 int ubdpt_read_sum_slot(ubdpt_context* c, uint32_t slot, double* rgb, int add_into) {
     if (!c || !rgb || slot >= c->pass_slots) return UBDPT_INVALID_ARG;
-    return readSumBuffer(c, 1 + slot, rgb, add_into);
+    return readSumBuffer(c, 1 + slot, add_into ? rgb : nullptr, rgb, 1);
+}
+
+int ubdpt_read_sum_slot_onto(ubdpt_context* c, uint32_t slot, const double* base, double* out, uint32_t host_threads) {
+    if (!c || !out || slot >= c->pass_slots) return UBDPT_INVALID_ARG;
+    return readSumBuffer(c, 1 + slot, base, out, host_threads);
 }
 
 // uengine/uconverter.cpp:3-76: the fit functions and their sums over the three wavelength bins

@@ -50,9 +50,14 @@ bool HipRenderer::enqueueWindow(Window& w, size_t first_pass, uint32_t half) {
     return true;
 }
 
-bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t /*num_threads*/,
+bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t num_threads,
                              std::function<void(double)>& update_progress_callback) {
-    if (!m_ctx || !pixel_buffer) { m_status = UBDPT_UNINITIALIZED; return false; }
+    return renderPassOnto(pixel_buffer.get(), pixel_buffer, curr_pass, num_threads, update_progress_callback);
+}
+
+bool HipRenderer::renderPassOnto(const SumBuffer* prev, std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass,
+                                 size_t num_threads, std::function<void(double)>& update_progress_callback) {
+    if (!m_ctx || !pixel_buffer || !prev) { m_status = UBDPT_UNINITIALIZED; return false; }
     m_stop_requested = false;  // UBDPTRenderer::renderPass resets m_stop on entry (ubdptrenderer.cpp:37)
     if (!m_window.holds(curr_pass, m_seed)) {
         if (m_next_window.holds(curr_pass, m_seed)) {
@@ -67,8 +72,8 @@ bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t cur
             enqueueWindow(m_next_window, m_window.first + m_window.count, m_window.half ^ 1u);
     }
     // this pass is added to the caller's running sum (waits for the window the pass belongs to, not for the next one)
-    m_status = ubdpt_read_sum_slot(m_ctx, m_window.half * m_window_slots + (uint32_t)(curr_pass - m_window.first),
-                                   pixel_buffer->ptr(), 1);
+    m_status = ubdpt_read_sum_slot_onto(m_ctx, m_window.half * m_window_slots + (uint32_t)(curr_pass - m_window.first),
+                                        prev->ptr(), pixel_buffer->ptr(), (uint32_t)std::min<size_t>(std::max<size_t>(num_threads, 1), 16));
     if (m_status != UBDPT_SUCCESS) return false;
     if (m_stop_requested) {  // stop() arrived during this call
         m_status = UBDPT_STOPPED;
@@ -199,10 +204,12 @@ Result HipEngine::loadRendering(const std::string& filename, RenderParameters& p
 
 Result HipEngine::renderPass(size_t num_threads, std::function<void(double)> update_progress_callback) {
     if (!m_renderer) return Result::UUninitialized;
-    if (m_curr_pass != 0) m_buffers[m_write]->setFrom(*m_buffers[m_read]);
     if (num_threads <= 0) num_threads = 1;
     else if (num_threads > kMaxThreads) num_threads = kMaxThreads;
-    bool complete = m_renderer->renderPass(m_buffers[m_write], m_curr_pass, num_threads, update_progress_callback);
+    // the reference copies the read buffer into the write buffer and the renderer adds the pass to it (uengine.cpp:153-164);
+    // here write = read + pass in one sweep (the first pass is added to the zeros the write buffer holds)
+    const SumBuffer* prev = m_curr_pass != 0 ? m_buffers[m_read].get() : m_buffers[m_write].get();
+    bool complete = m_renderer->renderPassOnto(prev, m_buffers[m_write], m_curr_pass, num_threads, update_progress_callback);
     if (complete) {
         m_curr_pass++;
         std::swap(m_read, m_write);

@@ -79,9 +79,15 @@ public:
 
     // URenderer::initialize (uengine/ubdptrenderer.cpp:7-33)
     bool initialize(const RenderParameters& render_params, std::shared_ptr<FlatSceneSource> scene);
-    // URenderer::renderPass (uengine/ubdptrenderer.cpp:35-81). num_threads is a CPU hint and ignored.
+    // URenderer::renderPass (uengine/ubdptrenderer.cpp:35-81). num_threads CPU threads (at most 16) add the finished
+    // pass to the buffer; the rendering itself runs on the device.
     bool renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t num_threads,
                     std::function<void(double)>& update_progress_callback);
+    // The same with the sum so far in another buffer: out = prev + the pass, in one sweep over the image. This is what
+    // UEngine::renderPass does in two (copy of the read buffer into the write buffer, uengine/uengine.cpp:153-156, then
+    // the renderer's +=); prev == out.get() is renderPass.
+    bool renderPassOnto(const SumBuffer* prev, std::shared_ptr<SumBuffer> out, size_t curr_pass, size_t num_threads,
+                        std::function<void(double)>& update_progress_callback);
     // URenderer::stop (uengine/ubdptrenderer.cpp:83-86); callable from another thread
     void stop();
 

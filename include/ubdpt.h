@@ -270,6 +270,14 @@ int ubdpt_render_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint32
                                  uint64_t pass_stride, uint64_t seed, uint32_t* passes_done);
 int ubdpt_read_sum_slot(ubdpt_context* ctx, uint32_t slot, double* rgb, int add_into);
 /*
+ * out[i] = base[i] + per-pass buffer `slot`, the add running on up to host_threads CPU threads (1..16; the count
+ * URenderer::renderPass is given, uengine/uengine.cpp:158-164). With base = the engine's read buffer and out = its
+ * write buffer this is UEngine::renderPass's copy of the finished sum (uengine/uengine.cpp:153-156) and the renderer's
+ * += of one pass (uengine/ubdptrenderer.cpp:144,153) in one sweep over the image; base may be out (the += alone);
+ * base = NULL delivers the pass itself.
+ */
+int ubdpt_read_sum_slot_onto(ubdpt_context* ctx, uint32_t slot, const double* base, double* out, uint32_t host_threads);
+/*
  * The same, enqueued without waiting for the GPU, into per-pass buffers first_slot .. first_slot + n_passes - 1
  * (first_slot + n_passes <= pass_slots), so that the device renders the next window of passes into one half of
  * the buffers while the host consumes the other half (the reference's counterpart: the render loop on its own thread,

@@ -399,6 +399,41 @@ def test_separate_passes_equal_the_passes_rendered_alone(pipeline):
     assert np.allclose(sum(slots), window, rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("size", [(40, 40), (700, 520)])
+def test_pass_added_onto_another_buffer_equals_copy_then_add(size):
+    """ubdpt_read_sum_slot_onto delivers base + pass: the copy of the finished sum and the += of one pass that
+    UEngine::renderPass and the renderer do in two sweeps (uengine/uengine.cpp:153-164). Bitwise equal to
+    numpy's base + pass for one and for several host threads (the larger image is past the size from which the
+    add is split over threads), in place, and with no base at all."""
+    w, h = size
+    scene = SCENES["C2"]()
+    scene.desc.camera.ratio = float(w) / float(h)
+    params = scenes.make_params(w, h)
+    opt = capi.Options()
+    opt.pass_slots = 2
+    rng = np.random.default_rng(5)
+    base = rng.uniform(0.0, 3.0, (h, w, 3))
+    with capi.Context(scene, params, opt) as ctx:
+        st, done = ctx.render_passes_separate(4, 2, SEED)
+        assert st == capi.SUCCESS and done == 2
+        for slot in (0, 1):
+            one = ctx.read_sum_slot(slot)
+            assert one.sum() > 0
+            want = base + one
+            for threads in (1, 5, 16, 1000):
+                out = np.full((h, w, 3), -7.0)
+                ctx.read_sum_slot_onto(slot, base, out, threads)
+                assert np.array_equal(out, want), (slot, threads)
+            inplace = base.copy()
+            ctx.read_sum_slot_onto(slot, inplace, inplace, 4)
+            assert np.array_equal(inplace, want)
+            plain = np.full((h, w, 3), -7.0)
+            ctx.read_sum_slot_onto(slot, None, plain, 4)
+            assert np.array_equal(plain, one)
+        with pytest.raises(Exception):
+            ctx.read_sum_slot_onto(2, base, np.zeros((h, w, 3)), 1)
+
+
 def test_enqueued_windows_in_two_halves_equal_the_waited_form():
     """ubdpt_enqueue_passes_separate fills one half of the per-pass buffers while the other half is read: every
     buffer must equal the same pass rendered by the waited form, also when a half is re-used for a third window

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the reference-shaped interface: HipEngine::renderPass hands a HOST sum
 buffer to the renderer every pass (device clear, one pass, read-back, add on the host), against
-HipEngine::renderPasses, which keeps the sum on the device. C2 at 512x512."""
+HipEngine::renderPasses, which keeps the sum on the device: python tools/host_pass_rate.py [config, default C2]."""
 import importlib
 import os
 import sys
@@ -12,20 +12,22 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("bidirectional-pathtracing_amd")
 hostapi = importlib.import_module("bidirectional-pathtracing_amd.hostapi")
 
-sc, params, _ = pkg.scenes.make_config("C2")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+sc, params, _ = pkg.scenes.make_config(cfg)
 npix = int(params.img_res_x * params.img_res_y)
 with hostapi.Engine(sc) as eng:
     assert eng.new_rendering(params) == 0
     for _ in range(4):
         eng.render_pass()
     t = time.perf_counter()
-    n = 32
+    n = 32 if npix < (1 << 20) else 12
     for _ in range(n):
         assert eng.render_pass() == 0
     dt = time.perf_counter() - t
     print(f"pass-by-pass through the host buffer: {npix * n / dt / 1e6:.1f} Mpaths/s ({dt / n * 1e3:.2f} ms per pass)")
-    eng.render_passes(16)
+    nb = 256 if npix < (1 << 20) else 32
+    eng.render_passes(16 if npix < (1 << 20) else 4)
     t = time.perf_counter()
-    assert eng.render_passes(256) == 0
+    assert eng.render_passes(nb) == 0
     dt = time.perf_counter() - t
-    print(f"batched, sum resident on the device: {npix * 256 / dt / 1e6:.1f} Mpaths/s")
+    print(f"batched, sum resident on the device: {npix * nb / dt / 1e6:.1f} Mpaths/s")
