@@ -30,8 +30,8 @@ public:
     }
 
     // The buffer already holds the sum of all previous passes (uengine.cpp:153-156); add exactly one
-    // sample per pixel for pass curr_pass. num_threads is a CPU hint and ignored.
-    bool renderPass(std::shared_ptr<UBuffer2D<glm::dvec3>> pixel_buffer, size_t curr_pass, size_t,
+    // sample per pixel for pass curr_pass. The device renders; num_threads CPU threads add the pass to the buffer.
+    bool renderPass(std::shared_ptr<UBuffer2D<glm::dvec3>> pixel_buffer, size_t curr_pass, size_t num_threads,
                     std::function<void(double)>& update_progress_callback) override
     {
         // One pass is a small batch for the device, so a window of kSlots consecutive passes is rendered at once
@@ -54,7 +54,8 @@ public:
             {   m_next_first = m_win_first + kSlots; m_next_n = done; }
         }
         // UBuffer2D<glm::dvec3> is contiguous [y][x] of 3 doubles (uutils.h:37-98)
-        if(ubdpt_read_sum_slot(m_ctx, m_half * kSlots + uint32_t(curr_pass - m_win_first), reinterpret_cast<double*>(pixel_buffer->ptr()), /*add_into*/1) != UBDPT_SUCCESS) return false;
+        double* sum = reinterpret_cast<double*>(pixel_buffer->ptr());  // += of the pass on the threads this call was given
+        if(ubdpt_read_sum_slot_onto(m_ctx, m_half * kSlots + uint32_t(curr_pass - m_win_first), sum, sum, uint32_t(num_threads)) != UBDPT_SUCCESS) return false;
         if(update_progress_callback != nullptr) { std::lock_guard<std::mutex> l(m_progress); update_progress_callback(1.0); }
         return true;
     }
