@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -859,7 +860,11 @@ static void addOnto(const double* base, const double* add, double* out, uint64_t
     for (unsigned t = 1; t < threads; t++) {
         const uint64_t a = (uint64_t)t * per;
         if (a >= n) break;
-        pool.emplace_back(body, a, std::min(n, a + per));
+        try {
+            pool.emplace_back(body, a, std::min(n, a + per));
+        } catch (const std::exception&) {  // no thread to be had: this range runs here
+            body(a, std::min(n, a + per));
+        }
     }
     body(0, std::min(n, per));
     for (auto& th : pool) th.join();
