@@ -687,6 +687,9 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         A.S = c->S;
         A.E = B.E; A.L = B.L;
         A.E.n = A.L.n = nbatch;
+        // the wavefront pipeline keeps the live count words inside the carry records (below); the stores' own dense
+        // arrays take the count words of the finished subpaths
+        A.fin_E = B.E.count; A.fin_L = B.L.count;
         // per-pass buffers: pass j of the call adds into buffer 1 + first_slot + j (the kernels see the sum buffers
         // shifted by first_slot buffers and take j modulo the buffers that remain, which is j)
         A.fb = c->d_fb + (separate ? 3 * c->npix * (uint64_t)first_slot : 0);

@@ -37,6 +37,10 @@ struct RenderArgs {
     uint8_t* ray_flag;       // one per ray: 1 = nothing blocks it
     uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
     uint32_t* wf_count;      // [depth][16]: [d][0] length of the depth's trace queue, [d][3] the position the persistent waves claim chunks at; zeroed before every batch
+    // The count word of every eye / light subpath once more, written when the subpath ends, 4 bytes apart: the pair
+    // enumeration reads two words per pixel-sample, and out of the carry records each of them costs a whole line.
+    uint32_t* fin_E;
+    uint32_t* fin_L;
 };
 
 constexpr uint32_t kMaxWfDepth = 30;  // most bounces that can run as wavefront launches before the tail loop takes over

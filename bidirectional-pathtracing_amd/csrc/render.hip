@@ -593,7 +593,8 @@ DEV void connectPair(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, St
 
 // One lane per pixel-sample: appends its connectable (s,t) pairs to the pair queue. The specular
 // bits of the first kMaskedVertices vertices travel in the subpath's count word, so the common case
-// reads two words per pixel-sample; queue space is reserved with one atomic per workgroup.
+// reads two words per pixel-sample (from the dense copies the subpath kernels write when a subpath ends:
+// consecutive lanes read consecutive words); queue space is reserved with one atomic per workgroup.
 // A pixel-sample whose pairs no longer fit the queue goes to a list instead (A.wf_trace_q, free once the subpaths
 // are complete; its length is A.ray_count[2]) and k_pair_overflow evaluates its pairs one by one: same result,
 // and this kernel stays small (the slow path inside it cost it three quarters of its occupancy).
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     const PathStore& L = A.L;
     uint32_t mE = 0, mL = 0, nE = 0, nL = 0, cE = 0, cL = 0;
     if (active) {
-        mE = E.meta(gid); mL = L.meta(gid);
+        mE = A.fin_E[gid]; mL = A.fin_L[gid];
         nE = mE & 0xff; nL = mL & 0xff;
         for (uint32_t t = 0; t < nE; t++) cE += E.connectable(mE, t, gid) ? 1u : 0u;
         for (uint32_t s = 0; s < nL; s++) cL += L.connectable(mL, s, gid) ? 1u : 0u;

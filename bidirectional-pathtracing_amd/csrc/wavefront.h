@@ -115,10 +115,10 @@ DEV Rng pathRng(const RenderArgs& A, uint64_t i, bool light, uint64_t& pixel) {
 // that would fail them is not traced again, and what the reference would compute from the last TWO
 // vertices after the next hit is computed now, while both are in registers, and carried in `cy`.
 // Returns true when a vertex was pushed and the subpath goes on; `cy` then describes the next ray.
-// n = subpath.size() on entry, updated on push.
+// n = subpath.size() and meta = the subpath's count word on entry, both updated on push.
 template <bool STATS, bool LIGHT>
-DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& rng, uint32_t& n, const Closest& hit,
-                   int lobe, Carry& cy, Tally& ty) {
+DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& rng, uint32_t& n, uint32_t& meta,
+                   const Closest& hit, int lobe, Carry& cy, Tally& ty) {
     const DScene& S = A.S;
     const PathStore& P = LIGHT ? A.L : A.E;
     uint64_t npix = (uint64_t)S.img_res_x * S.img_res_y;
@@ -128,7 +128,6 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     surfacePoint(S, ray, hit, nv.sp);
     nv.sp.lobe = lobe;
     nv.p_light_A = 0; nv.p_eye_A = 0; nv.specular = false;
-    const uint32_t meta = P.meta(i);
     Tail cur;
     cur.pos = cy.pos;
     cur.Ns = cy.Ns;
@@ -186,7 +185,8 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     }
     storeVertex(P, n, i, nv);
     n++;
-    P.setMeta(i, ((meta & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n);
+    meta = ((meta & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n;
+    P.setMeta(i, meta);
     // the head of the next loop iteration (:346-356 / :537-547), n being the new size
     double fs_sum = fs.x + fs.y + fs.z;
     if (!(p_psa > 0) || !(fs_sum > 0)) return false;
@@ -318,7 +318,8 @@ __global__ __launch_bounds__(kBlock, 2) void k_wf_tail(RenderArgs A0, uint32_t d
         bool light = id >= N;
         uint64_t i = light ? id - N : id;
         const PathStore& P = light ? A.L : A.E;
-        uint32_t n = P.cnt(i);
+        uint32_t meta = P.meta(i);
+        uint32_t n = meta & 0xffu;
         uint64_t pixel;
         Rng rng = pathRng(A, i, light, pixel);
         Carry cy;
@@ -330,10 +331,11 @@ __global__ __launch_bounds__(kBlock, 2) void k_wf_tail(RenderArgs A0, uint32_t d
             if (hit.object < 0) break;
             int lobe = pickLobe(S.objects[hit.object], rng(hitDim(n, DIM_LOBE)));
             if (light && lobe == LOBE_NONE) break;
-            bool cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
-                              : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
+            bool cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, meta, hit, lobe, cy, ty)
+                              : shadeStep<STATS, false>(A, i, pixel, rng, n, meta, hit, lobe, cy, ty);
             if (!cont) break;
         }
+        (light ? A.fin_L : A.fin_E)[i] = meta;  // the subpath is complete
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);
     if (st.overflowed) atomicAdd(&A.counters[C_STACK_OVERFLOW], 1ULL);

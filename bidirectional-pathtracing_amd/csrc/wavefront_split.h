@@ -408,7 +408,8 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
             const bool light = id >= N;
             const uint64_t i = light ? id - N : id;
             const PathStore& P = light ? A.L : A.E;
-            const uint32_t n = P.cnt(i);
+            const uint32_t m = P.meta(i);
+            const uint32_t n = m & 0xffu;
             if (n > 0) {
                 const unsigned long long w = (unsigned long long)__double_as_longlong(A.wf_hit[(uint64_t)id * kHitDoubles + 3]);
                 const int32_t object = (int32_t)(uint32_t)w;
@@ -419,6 +420,7 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
                     if (!(light && lobe == LOBE_NONE)) region = (light ? 4 : 0) + lobe + 1;
                 }
             }
+            if (region == kWfRegions) (light ? A.fin_L : A.fin_E)[i] = m;  // the subpath ends here
         }
         // stable counting sort of the chunk by region
         uint32_t rank = 0;
@@ -450,16 +452,18 @@ __global__ __launch_bounds__(kBlock, UBDPT_SHADE_WAVES) void k_wf_shade(RenderAr
             const int lobe = (int)(r & 3) - 1;
             const uint64_t i = light ? sid - N : sid;
             const PathStore& P = light ? A.L : A.E;
-            uint32_t n = P.cnt(i);
+            uint32_t meta = P.meta(i);
+            uint32_t n = meta & 0xffu;
             uint64_t pixel;
             Rng rng = pathRng(A, i, light, pixel);
             Carry cy;
             loadCarry(A, sid, cy, !light && n == 1);
             Closest hit;
             loadHit(A, sid, hit);
-            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, hit, lobe, cy, ty)
-                         : shadeStep<STATS, false>(A, i, pixel, rng, n, hit, lobe, cy, ty);
+            cont = light ? shadeStep<STATS, true>(A, i, pixel, rng, n, meta, hit, lobe, cy, ty)
+                         : shadeStep<STATS, false>(A, i, pixel, rng, n, meta, hit, lobe, cy, ty);
             if (cont) storeCarry(A, sid, cy);
+            else (light ? A.fin_L : A.fin_E)[i] = meta;  // the subpath is complete
         }
         uint32_t pos = blockAppend(cont, &next_cnt[0], s_wave, &s_base);  // ends with a barrier: s_sorted / s_wcnt are free again
         if (cont) next_q[pos] = sid;
