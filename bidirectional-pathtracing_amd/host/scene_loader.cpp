@@ -1,6 +1,8 @@
 // scene_loader.cpp — see scene_loader.h.
 #include "scene_loader.h"
 
+#include "asset_formats.h"
+
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -165,7 +167,9 @@ M4 rotate(const M4& m, double angle, const double v[3]) {  // glm::rotate(m, ang
 }
 
 // ---- Wavefront OBJ -> triangle soup in the conventions the reference requests from its importer ------
-struct V3 { double x, y, z; };
+using formats::Corner;
+using formats::MeshSoup;
+using formats::V3;
 V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 V3 add(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 V3 mul(V3 a, double s) { return {a.x * s, a.y * s, a.z * s}; }
@@ -176,20 +180,19 @@ V3 normalized(V3 a) {
     return l > 0 ? mul(a, 1.0 / l) : V3{0, 0, 0};
 }
 
-// Reads a Wavefront OBJ file into triangle corners appended to `out`; `part_faces` receives the face count of
-// each model the file yields, in order. The reference hands every aiMesh of the imported file to its own
+// Reads a Wavefront OBJ file: positions, normals and texture coordinates as listed, and per model three corners per
+// triangle. The reference hands every aiMesh of the imported file to its own
 // Object/Emitter (uapp/scene.cpp:181-190, :284-327); the importer makes one mesh per `o` object and material
 // and, with aiProcess_OptimizeMeshes, joins the `g` groups of one object that share a material. The importer
 // itself is a third-party library that is not part of the reference tree, so this division (and the order of
 // the parts: first appearance in the file) restates its documented behaviour and is not pinned by a fixture.
-bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::vector<size_t>& part_faces,
-             std::string& error) {
+bool parseObj(const std::string& path, MeshSoup& soup, std::string& error) {
     std::ifstream in(path);
     if (!in.is_open()) { error = "cannot open mesh file " + path; return false; }
-    std::vector<V3> pos, nrm;
-    std::vector<std::pair<double, double>> uv;
-    struct Corner { int p, t, n; };
-    std::vector<std::vector<Corner>> parts;  // per model: 3 corners per triangle
+    std::vector<V3>& pos = soup.pos;
+    std::vector<V3>& nrm = soup.nrm;
+    std::vector<std::pair<double, double>>& uv = soup.uv;
+    std::vector<std::vector<Corner>>& parts = soup.parts;  // per model: 3 corners per triangle
     std::map<std::pair<int, std::string>, size_t> part_of;
     int object_index = 0;
     std::string material;
@@ -233,13 +236,23 @@ bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::
         }
     }
     if (parts.empty()) { error = "mesh has no faces: " + path; return false; }
-    for (const std::vector<Corner>& corners : parts)
+    return true;
+}
+
+// The importer's post-processing of a mesh file's models, restated: triangle corners appended to `out`, `part_faces`
+// receives the face count of each model in order.
+bool emitModels(const std::string& path, const MeshSoup& soup, std::vector<ubdpt_mesh_vertex>& out,
+                std::vector<size_t>& part_faces, std::string& error) {
+    const std::vector<V3>& pos = soup.pos;
+    const std::vector<V3>& nrm = soup.nrm;
+    const std::vector<std::pair<double, double>>& uv = soup.uv;
+    for (const std::vector<Corner>& corners : soup.parts)
         for (const Corner& c : corners)
-            if (c.p < 1 || c.p > (int)pos.size() || c.t > (int)uv.size() || c.n > (int)nrm.size()) {
+            if (c.p < 1 || c.p > (int)pos.size() || c.t < 0 || c.t > (int)uv.size() || c.n < 0 || c.n > (int)nrm.size()) {
                 error = "face index out of range in " + path;
                 return false;
             }
-    for (const std::vector<Corner>& corners : parts) {
+    for (const std::vector<Corner>& corners : soup.parts) {
         // aiProcess_GenSmoothNormals when the file has none: area-weighted face normals summed per position,
         // within one model (the importer smooths each mesh on its own)
         std::vector<V3> smooth;
@@ -290,7 +303,25 @@ bool loadObj(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::
     return true;
 }
 
-// binary PPM (P6, maxval 255) -> RGBA8888 rows, alpha 255
+// A mesh file by its extension: Wavefront OBJ, Stanford PLY, STL. (The reference's importer knows more formats; these
+// are the ones restated here, asset_formats.h.)
+bool loadMesh(const std::string& path, std::vector<ubdpt_mesh_vertex>& out, std::vector<size_t>& part_faces,
+              std::string& error) {
+    MeshSoup soup;
+    const std::string ext = formats::lowerExtension(path);
+    bool ok;
+    if (ext == "ply") ok = formats::parsePly(path, soup, error);
+    else if (ext == "stl") ok = formats::parseStl(path, soup, error);
+    else ok = parseObj(path, soup, error);
+    return ok && emitModels(path, soup, out, part_faces, error);
+}
+
+// An image file as RGBA8888 rows from the top: Netpbm here, PNG / BMP / TGA in asset_formats.cpp.
+bool loadPpm(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba);
+bool loadTexture(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
+    return loadPpm(path, w, h, rgba) || formats::loadImageFile(path, w, h, rgba);
+}
+
 // Netpbm images with 8-bit samples: P6 / P3 (colour, binary / text) and P5 / P2 (grey, binary / text), as RGBA8888
 // (what TextureImg keeps of a QImage, uapp/textureimg.cpp:19-33).
 bool loadPpm(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
@@ -361,7 +392,7 @@ struct SceneBuilderAccess {
             else {
                 uint32_t w = 0, h = 0;
                 std::vector<uint8_t> rgba;
-                if (loadPpm(joinPath(base_dir, file), w, h, rgba)) {
+                if (loadTexture(joinPath(base_dir, file), w, h, rgba)) {
                     ubdpt_texture t{};
                     t.kind = UBDPT_TEX_IMAGE; t.width = w; t.height = h; t.texel_offset = s.m_texels.size();
                     s.m_texels.insert(s.m_texels.end(), rgba.begin(), rgba.end());
@@ -416,7 +447,7 @@ struct SceneBuilderAccess {
             M4 T = scale(rotate(translate(identity(), trans), angle, rot), scl);
             size_t first_face = s.m_vertices.size() / 3;
             std::vector<size_t> part_faces;
-            if (!xf || !loadObj(joinPath(base_dir, xf->text), s.m_vertices, part_faces, error)) {
+            if (!xf || !loadMesh(joinPath(base_dir, xf->text), s.m_vertices, part_faces, error)) {
                 if (error.empty()) error = "Failed to load scene.";
                 return false;
             }

@@ -217,6 +217,194 @@ def test_texture_file_formats(tmp_path):
     assert all(np.array_equal(g5[..., k], grey) for k in range(3)) and (g5[..., 3] == 255).all()
 
 
+def _png(img, ctype, depth=8, interlace=False, palette=None, filters=(0, 1, 2, 3, 4)):
+    """A PNG file of `img` ([H][W][channels] sample values at `depth` bits) written by hand: every row with another
+    filter type, optionally Adam7-interlaced."""
+    import struct, zlib
+    H, W = img.shape[:2]
+    ch = img.shape[2]
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    def pack_rows(sub):
+        h, w = sub.shape[:2]
+        rows = []
+        for y in range(h):
+            v = sub[y].reshape(-1)
+            if depth == 16:
+                b = b"".join(struct.pack(">H", int(x)) for x in v)
+            elif depth == 8:
+                b = bytes(int(x) for x in v)
+            else:
+                bits = "".join(format(int(x), "0%db" % depth) for x in v)
+                bits += "0" * (-len(bits) % 8)
+                b = bytes(int(bits[k:k + 8], 2) for k in range(0, len(bits), 8))
+            rows.append(bytearray(b))
+        bpp = max(1, ch * depth // 8)
+        out = bytearray()
+        for y, cur in enumerate(rows):
+            ft = filters[y % len(filters)]
+            up = rows[y - 1] if y else bytearray(len(cur))
+            enc = bytearray(len(cur))
+            for x in range(len(cur)):
+                a = cur[x - bpp] if x >= bpp else 0
+                b_ = up[x]
+                c = up[x - bpp] if x >= bpp else 0
+                if ft == 0: pr = 0
+                elif ft == 1: pr = a
+                elif ft == 2: pr = b_
+                elif ft == 3: pr = (a + b_) // 2
+                else:
+                    pp = a + b_ - c
+                    pa, pb, pc = abs(pp - a), abs(pp - b_), abs(pp - c)
+                    pr = a if (pa <= pb and pa <= pc) else (b_ if pb <= pc else c)
+                enc[x] = (cur[x] - pr) & 255
+            out += bytes([ft]) + enc
+        return bytes(out)
+    if interlace:
+        raw = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = img[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += pack_rows(sub)
+    else:
+        raw = pack_rows(img)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(int(x) for x in palette.reshape(-1)))
+    half = len(zlib.compress(raw)) // 2
+    z = zlib.compress(raw)
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+def test_image_file_formats(tmp_path):
+    """PNG (every colour type, 1 to 16 bits, plain and interlaced, every row filter), BMP (24 / 32 / 8-bit palette,
+    bottom-up and top-down) and TGA (plain, run-length coded, grey) textures give the texels of the same image as a
+    PPM file. The reference reads images through QImage, which is not available here: the expected texels are
+    written down from the file format definitions (RGBA8888, rows from the top), not produced by the reference."""
+    import struct
+    img = write_files(tmp_path)                      # 6 x 8 x 3, uint8
+    H, W = img.shape[:2]
+    rng = np.random.default_rng(5)
+    alpha = rng.integers(0, 256, (H, W, 1), dtype=np.uint8)
+    def texels(name, shape=(H, W)):
+        (tmp_path / "s.xml").write_text(XML.replace("checker.ppm", name))
+        xs = hostapi.XmlScene(str(tmp_path / "s.xml"), str(tmp_path))
+        n = xs.desc.num_texel_bytes
+        return np.frombuffer(bytes(bytearray(xs.desc.texels[k] for k in range(n))), np.uint8).reshape(shape + (4,))
+    def write(name, data):
+        with open(tmp_path / name, "wb") as f:
+            f.write(data)
+    rgba = np.concatenate([img, alpha], axis=2)
+    opaque = np.concatenate([img, np.full((H, W, 1), 255, np.uint8)], axis=2)
+    # PNG: true colour, with alpha, interlaced
+    write("rgb.png", _png(img, 2)); write("rgba.png", _png(rgba, 6)); write("rgb_i.png", _png(img, 2, interlace=True))
+    assert np.array_equal(texels("rgb.png"), opaque)
+    assert np.array_equal(texels("rgba.png"), rgba)
+    assert np.array_equal(texels("rgb_i.png"), opaque)
+    # 16 bits per sample are rounded to 8
+    wide = rng.integers(0, 65536, (H, W, 3)).astype(np.uint32)
+    write("rgb16.png", _png(wide, 2, depth=16))
+    assert np.array_equal(texels("rgb16.png")[..., :3], ((wide * 255 + 32767) // 65535).astype(np.uint8))
+    # grey at 8, 4 and 1 bits, grey with alpha, palette at 8 and 2 bits (interlaced)
+    grey = img[..., :1]
+    write("g8.png", _png(grey, 0))
+    assert all(np.array_equal(texels("g8.png")[..., k], grey[..., 0]) for k in range(3))
+    g4 = rng.integers(0, 16, (H, W, 1)); g1 = rng.integers(0, 2, (H, W, 1))
+    write("g4.png", _png(g4, 0, depth=4)); write("g1.png", _png(g1, 0, depth=1, interlace=True))
+    assert np.array_equal(texels("g4.png")[..., 1], (g4[..., 0] * 17).astype(np.uint8))
+    assert np.array_equal(texels("g1.png")[..., 2], (g1[..., 0] * 255).astype(np.uint8))
+    write("ga.png", _png(np.concatenate([grey, alpha], axis=2), 4))
+    t = texels("ga.png")
+    assert np.array_equal(t[..., 0], grey[..., 0]) and np.array_equal(t[..., 3], alpha[..., 0])
+    pal = rng.integers(0, 256, (256, 3), dtype=np.uint8)
+    idx8 = rng.integers(0, 256, (H, W, 1)); idx2 = rng.integers(0, 4, (H, W, 1))
+    write("p8.png", _png(idx8, 3, palette=pal)); write("p2.png", _png(idx2, 3, depth=2, palette=pal[:4], interlace=True))
+    assert np.array_equal(texels("p8.png")[..., :3], pal[idx8[..., 0]])
+    assert np.array_equal(texels("p2.png")[..., :3], pal[idx2[..., 0]])
+    # BMP: 24 bits bottom-up (rows padded to four bytes), 32 bits top-down, 8-bit palette
+    def bmp(bpp, rows, height, palette=b""):
+        data = b"".join(r + b"\0" * (-len(r) % 4) for r in rows)
+        off = 14 + 40 + len(palette)
+        return (b"BM" + struct.pack("<IHHI", off + len(data), 0, 0, off)
+                + struct.pack("<IiiHHIIiiII", 40, W, height, 1, bpp, 0, len(data), 2835, 2835, len(palette) // 4, 0) + palette + data)
+    write("c24.bmp", bmp(24, [img[y, :, ::-1].tobytes() for y in range(H - 1, -1, -1)], H))
+    write("c32.bmp", bmp(32, [np.concatenate([img[y, :, ::-1], alpha[y]], axis=1).tobytes() for y in range(H)], -H))
+    palb = b"".join(bytes([int(c[2]), int(c[1]), int(c[0]), 0]) for c in pal)
+    write("p8.bmp", bmp(8, [bytes(int(v) for v in idx8[y, :, 0]) for y in range(H - 1, -1, -1)], H, palb))
+    assert np.array_equal(texels("c24.bmp"), opaque)
+    assert np.array_equal(texels("c32.bmp"), opaque)                  # the fourth byte of an uncompressed 32-bit file is not alpha
+    assert np.array_equal(texels("p8.bmp")[..., :3], pal[idx8[..., 0]])
+    # TGA: 24 bits from the bottom, 32 bits run-length coded from the top, grey
+    def tga(kind, bpp, desc, body):
+        return struct.pack("<BBBHHBHHHHBB", 0, 0, kind, 0, 0, 0, 0, 0, W, H, bpp, desc) + body
+    write("c24.tga", tga(2, 24, 0, b"".join(img[y, :, ::-1].tobytes() for y in range(H - 1, -1, -1))))
+    flat = np.concatenate([img[..., ::-1], alpha], axis=2).reshape(-1, 4)
+    flat[8:13] = flat[8]                                               # a run for the run-length packets
+    body, k = b"", 0
+    while k < len(flat):
+        run = 1
+        while k + run < len(flat) and run < 128 and np.array_equal(flat[k + run], flat[k]):
+            run += 1
+        if run > 1:
+            body += bytes([128 | (run - 1)]) + flat[k].tobytes(); k += run
+        else:
+            n = min(3, len(flat) - k)
+            body += bytes([n - 1]) + flat[k:k + n].tobytes(); k += n
+    write("c32.tga", tga(10, 32, 0x28, body))
+    write("g8.tga", tga(3, 8, 0x20, grey.tobytes()))
+    assert np.array_equal(texels("c24.tga"), opaque)
+    assert np.array_equal(texels("c32.tga"), flat[:, [2, 1, 0, 3]].reshape(H, W, 4))
+    assert all(np.array_equal(texels("g8.tga")[..., k], grey[..., 0]) for k in range(3))
+    # a damaged file is an error, not a crash
+    write("cut.png", _png(img, 2)[:-40])
+    (tmp_path / "cut.xml").write_text(XML.replace("checker.ppm", "cut.png"))
+    with pytest.raises(RuntimeError, match="Failed to load texture"):
+        hostapi.XmlScene(str(tmp_path / "cut.xml"), str(tmp_path))
+
+
+def test_mesh_file_formats(tmp_path):
+    """The floor quad as PLY (text, little and big endian, with an element and properties the loader skips) and the
+    light quad as STL (text and binary) give the vertices of the OBJ files. The importer of the reference is not
+    available here: what the files must yield follows from the format definitions and the post-processing the
+    reference asks for (left-handed coordinates, fan triangulation), not from a reference run."""
+    import struct
+    write_files(tmp_path)
+    base = hostapi.XmlScene(str(tmp_path / "scene.xml"), str(tmp_path)).vertices()
+    pts = [(-1, -1, 1, 0, 1, 0, 0, 0), (1, -1, 1, 0, 1, 0, 1, 0), (1, -1, -1, 0, 1, 0, 1, 1), (-1, -1, -1, 0, 1, 0, 0, 1)]
+    header = ("ply\nformat %s 1.0\ncomment floor\nelement vertex 4\nproperty float x\nproperty float y\nproperty double z\n"
+              "property float nx\nproperty float ny\nproperty float nz\nproperty uchar red\nproperty float s\nproperty float t\n"
+              "element face 1\nproperty uchar flags\nproperty list uchar int vertex_indices\n"
+              "element edge 1\nproperty int a\nproperty list ushort short extra\nend_header\n")
+    text = header % "ascii" + "".join("%g %g %g %g %g %g 7 %g %g\n" % p for p in pts) + "9 4 0 1 2 3\n5 2 1 2\n"
+    (tmp_path / "floor_a.ply").write_text(text)
+    for name, e in (("floor_l.ply", "<"), ("floor_b.ply", ">")):
+        body = b"".join(struct.pack(e + "ffdfffBff", p[0], p[1], p[2], p[3], p[4], p[5], 7, p[6], p[7]) for p in pts)
+        body += struct.pack(e + "BBiiii", 9, 4, 0, 1, 2, 3) + struct.pack(e + "iHhh", 5, 2, 1, 2)
+        with open(tmp_path / name, "wb") as f:
+            f.write((header % ("binary_little_endian" if e == "<" else "binary_big_endian")).encode() + body)
+    tris = [((-1, 0, 1), (1, 0, 1), (1, 0, -1)), ((-1, 0, 1), (1, 0, -1), (-1, 0, -1))]   # f 4 3 2 1 as a fan
+    (tmp_path / "light_a.stl").write_text("solid light\n" + "".join(
+        "facet normal 0 -1 0\n outer loop\n" + "".join("  vertex %g %g %g\n" % v for v in t) + " endloop\nendfacet\n" for t in tris)
+        + "endsolid light\n")
+    with open(tmp_path / "light_b.stl", "wb") as f:   # the second facet without a normal: the corners' own is used
+        f.write(b"binary stl".ljust(80, b" ") + struct.pack("<I", 2)
+                + struct.pack("<12fH", 0, -1, 0, *[c for v in tris[0] for c in v], 0)
+                + struct.pack("<12fH", 0, 0, 0, *[c for v in tris[1] for c in v], 0))
+    for floor in ("floor_a.ply", "floor_l.ply", "floor_b.ply"):
+        for light in ("light_a.stl", "light_b.stl"):
+            (tmp_path / "m.xml").write_text(XML.replace("floor.obj", floor).replace("light.obj", light))
+            xs = hostapi.XmlScene(str(tmp_path / "m.xml"), str(tmp_path))
+            v = xs.vertices()
+            assert v.shape == base.shape and xs.n_objects == 5
+            for field in ("pos", "uv"):
+                assert np.array_equal(v[field], base[field]), (floor, light, field)
+            assert np.allclose(v["normal"], base["normal"], atol=1e-7) and np.allclose(v["tangent"], base["tangent"], atol=1e-7)
+    (tmp_path / "bad.ply").write_text(header % "ascii" + "0 0 0\n")
+    (tmp_path / "bad.xml").write_text(XML.replace("floor.obj", "bad.ply"))
+    with pytest.raises(RuntimeError, match="bad.ply"):
+        hostapi.XmlScene(str(tmp_path / "bad.xml"), str(tmp_path))
+
+
 def test_loader_errors(tmp_path):
     write_files(tmp_path)
     with pytest.raises(RuntimeError, match="Failed to open scene file"):
