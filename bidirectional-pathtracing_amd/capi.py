@@ -105,7 +105,7 @@ class Stats(C.Structure):
 # Every entry point include/ubdpt.h declares; tests check that the library exports all of them.
 EXPORTS = [
     "ubdpt_version", "ubdpt_status_string", "ubdpt_device_count", "ubdpt_create", "ubdpt_destroy",
-    "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_request_stop", "ubdpt_read_sum",
+    "ubdpt_render_passes", "ubdpt_enqueue_passes", "ubdpt_synchronize", "ubdpt_query_progress", "ubdpt_request_stop", "ubdpt_read_sum",
     "ubdpt_read_sum_device", "ubdpt_accumulate_sum_device", "ubdpt_upload_sum", "ubdpt_image_rgb", "ubdpt_render_passes_separate", "ubdpt_read_sum_slot",
     "ubdpt_read_sum_slot_onto",
     "ubdpt_enqueue_passes_separate",
@@ -165,6 +165,7 @@ def load_library(path=None):
     lib.ubdpt_render_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_enqueue_passes.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_synchronize.argtypes = [vp]
+    lib.ubdpt_query_progress.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ubdpt_request_stop.argtypes = [vp]
     lib.ubdpt_render_passes_separate.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint32)]
     lib.ubdpt_read_sum_slot.argtypes = [vp, C.c_uint32, vp, C.c_int]
@@ -281,6 +282,12 @@ class Context:
 
     def synchronize(self):
         _check(self.lib.ubdpt_synchronize(self.handle), "ubdpt_synchronize")
+
+    def query_progress(self):
+        """(pixel-samples enqueued since the context was created, pixel-samples the GPU has finished)."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self.lib.ubdpt_query_progress(self.handle, C.byref(a), C.byref(b)), "ubdpt_query_progress")
+        return a.value, b.value
 
     def request_stop(self):
         _check(self.lib.ubdpt_request_stop(self.handle), "ubdpt_request_stop")

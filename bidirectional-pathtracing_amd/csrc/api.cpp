@@ -154,10 +154,12 @@ struct ubdpt_context {
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
         // one marker event per enqueued batch with pending.size() at that point: waiting for the oldest marker
         // bounds the host's lead over the device without draining the other lanes
-        std::deque<std::pair<hipEvent_t, size_t>> inflight;
+        struct Marker { hipEvent_t first; size_t second; uint64_t paths; };  // event, pending.size(), pixel-samples of the batch
+        std::deque<Marker> inflight;
     };
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
+    uint64_t paths_enqueued = 0;  // pixel-samples of all batches enqueued so far (ubdpt_query_progress)
     bool work_pending = false;    // batches were enqueued and not yet waited for
     double pending_since = 0;
     unsigned long long* d_counters = nullptr;
@@ -209,12 +211,13 @@ struct ubdpt_context {
     }
     void endTimedLane(BatchLane& b) { hipEventRecord(b.pending.back().stop, b.stream); }
     std::vector<hipEvent_t> marker_pool;
-    void markBatch(BatchLane& b) {
+    void markBatch(BatchLane& b, uint64_t paths) {
         hipEvent_t ev;
         if (!marker_pool.empty()) { ev = marker_pool.back(); marker_pool.pop_back(); }
         else hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         hipEventRecord(ev, b.stream);
-        b.inflight.emplace_back(ev, b.pending.size());
+        b.inflight.push_back(BatchLane::Marker{ev, b.pending.size(), paths});
+        paths_enqueued += paths;
     }
     // waits until at most max_inflight batches of the lane are unfinished
     hipError_t throttle(BatchLane& b, size_t max_inflight) {
@@ -764,7 +767,7 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
         batch++;
         // keep at most a few batches (about 16 M pixel-samples) queued per lane, so that a stop request is
         // honoured promptly and the host does not run arbitrarily far ahead of the device
-        c->markBatch(B);
+        c->markBatch(B, nbatch);
         const size_t max_inflight = (size_t)std::max<uint64_t>(2, std::min<uint64_t>(64, (16ull << 20) / std::max<uint64_t>(1, c->cap_paths)));
         HIPCK(c, c->throttle(B, max_inflight));
     }
@@ -801,6 +804,24 @@ int ubdpt_render_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
 int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
                          uint32_t* passes_enqueued) {
     return renderPasses(c, first_pass, n_passes, pass_stride, seed, passes_enqueued, false);
+}
+
+int ubdpt_query_progress(ubdpt_context* c, uint64_t* samples_enqueued, uint64_t* samples_finished) {
+    if (!c) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    uint64_t unfinished = 0;
+    for (auto& b : c->lanes) {
+        // a lane's batches finish in order: everything from the first marker that has not been reached is unfinished
+        bool reached = true;
+        for (auto& m : b.inflight) {
+            if (reached && hipEventQuery(m.first) != hipSuccess) reached = false;
+            if (!reached) unfinished += m.paths;
+        }
+    }
+    (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error status
+    if (samples_enqueued) *samples_enqueued = c->paths_enqueued;
+    if (samples_finished) *samples_finished = c->paths_enqueued - unfinished;
+    return UBDPT_SUCCESS;
 }
 
 int ubdpt_render_passes_separate(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride,

@@ -92,15 +92,45 @@ void HipRenderer::stop() {
     if (m_ctx) ubdpt_request_stop(m_ctx);
 }
 
-bool HipRenderer::renderPassesOnDevice(size_t first_pass, size_t n, size_t* done_out) {
+bool HipRenderer::renderPassesOnDevice(size_t first_pass, size_t n, size_t* done_out,
+                                       const std::function<void(double)>* progress) {
     if (done_out) *done_out = 0;
     if (!m_ctx) { m_status = UBDPT_UNINITIALIZED; return false; }
     size_t done_total = 0;
-    while (done_total < n) {
-        uint32_t chunk = (uint32_t)std::min<size_t>(n - done_total, 1u << 20), done = 0;
-        m_status = ubdpt_render_passes(m_ctx, first_pass + done_total, chunk, 1, m_seed, &done);
-        done_total += done;
-        if (m_status != UBDPT_SUCCESS) break;
+    if (!progress || !*progress) {
+        while (done_total < n) {
+            uint32_t chunk = (uint32_t)std::min<size_t>(n - done_total, 1u << 20), done = 0;
+            m_status = ubdpt_render_passes(m_ctx, first_pass + done_total, chunk, 1, m_seed, &done);
+            done_total += done;
+            if (m_status != UBDPT_SUCCESS) break;
+        }
+    } else {
+        // With a progress callback the passes are enqueued a few batches at a time (about 16 M pixel-samples per
+        // call) and the callback hears, after every call, which fraction of the n passes the GPU has finished
+        // (the reference reports finished pixels of its one pass, ubdptrenderer.cpp:54-62).
+        uint64_t w = 0, h = 0;
+        ubdpt_get_image_size(m_ctx, &w, &h);
+        const uint64_t npix = std::max<uint64_t>(1, (uint64_t)w * h);
+        const size_t per_call = (size_t)std::max<uint64_t>(1, std::min<uint64_t>(1u << 16, (16ull << 20) / npix));
+        uint64_t enq0 = 0, fin = 0;
+        ubdpt_query_progress(m_ctx, &enq0, nullptr);
+        const double total = (double)n * (double)npix;
+        while (done_total < n) {
+            uint32_t done = 0;
+            m_status = ubdpt_enqueue_passes(m_ctx, first_pass + done_total, (uint32_t)std::min(per_call, n - done_total), 1, m_seed, &done);
+            done_total += done;
+            if (m_status != UBDPT_SUCCESS) break;
+            if (ubdpt_query_progress(m_ctx, nullptr, &fin) == UBDPT_SUCCESS && fin >= enq0) {
+                std::lock_guard<std::mutex> lock(m_progress_mutex);
+                (*progress)(std::min(1.0, (double)(fin - enq0) / total));
+            }
+        }
+        const int sync = ubdpt_synchronize(m_ctx);
+        if (m_status == UBDPT_SUCCESS) m_status = sync;
+        if (m_status == UBDPT_SUCCESS) {
+            std::lock_guard<std::mutex> lock(m_progress_mutex);
+            (*progress)(1.0);
+        }
     }
     if (done_out) *done_out = done_total;
     return m_status == UBDPT_SUCCESS;
@@ -219,13 +249,13 @@ Result HipEngine::renderPass(size_t num_threads, std::function<void(double)> upd
                                                                                                      : Result::UError;
 }
 
-Result HipEngine::renderPasses(size_t n) {
+Result HipEngine::renderPasses(size_t n, std::function<void(double)> update_progress_callback) {
     if (!m_renderer) return Result::UUninitialized;
     if (n == 0) return Result::USuccess;
     // device sum := everything rendered so far, then n more passes on top, one read-back at the end
     if (!m_renderer->uploadSum(m_curr_pass != 0 ? m_buffers[m_read].get() : nullptr)) return Result::UError;
     size_t done = 0;
-    bool ok = m_renderer->renderPassesOnDevice(m_curr_pass, n, &done);
+    bool ok = m_renderer->renderPassesOnDevice(m_curr_pass, n, &done, &update_progress_callback);
     if (!ok && m_renderer->lastStatus() != UBDPT_STOPPED) return Result::UError;
     if (done > 0) {
         if (!m_renderer->readSum(*m_buffers[m_write], false)) return Result::UError;
@@ -275,6 +305,11 @@ int uhip_engine_render_pass(uhip_engine* e, size_t num_threads, void (*progress)
     return (int)e->engine.renderPass(num_threads, cb);
 }
 int uhip_engine_render_passes(uhip_engine* e, size_t n) { return (int)e->engine.renderPasses(n); }
+int uhip_engine_render_passes_progress(uhip_engine* e, size_t n, void (*progress)(double)) {
+    std::function<void(double)> cb;
+    if (progress) cb = progress;
+    return (int)e->engine.renderPasses(n, cb);
+}
 void uhip_engine_stop(uhip_engine* e) { e->engine.stop(); }
 size_t uhip_engine_curr_pass(uhip_engine* e) { return e->engine.currPass(); }
 int uhip_engine_sum(uhip_engine* e, double* out) {

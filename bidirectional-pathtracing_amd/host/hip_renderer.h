@@ -92,8 +92,10 @@ public:
     void stop();
 
     // Batched form: passes [first_pass, first_pass + n) accumulate in the device sum buffer; nothing
-    // crosses PCIe until readSum. `done` receives the passes finished when a stop arrived.
-    bool renderPassesOnDevice(size_t first_pass, size_t n, size_t* done = nullptr);
+    // crosses PCIe until readSum. `done` receives the passes finished when a stop arrived. With a progress callback
+    // the passes are enqueued a few batches at a time and the callback is told the finished fraction of the n passes.
+    bool renderPassesOnDevice(size_t first_pass, size_t n, size_t* done = nullptr,
+                              const std::function<void(double)>* progress = nullptr);
     bool uploadSum(const SumBuffer* sum);              // nullptr clears the device sum
     bool readSum(SumBuffer& out, bool add_into);
     void setSeed(uint64_t seed) { m_seed = seed; }
@@ -139,7 +141,7 @@ public:
     Result loadRendering(const std::string& filename, RenderParameters& params, RendererType& type, size_t& curr_pass);  // :88-142
     Result renderPass(size_t num_threads, std::function<void(double)> update_progress_callback);      // :144-180
     // n passes with the sum resident on the device; the host sum buffer is refreshed once at the end
-    Result renderPasses(size_t n);
+    Result renderPasses(size_t n, std::function<void(double)> update_progress_callback = nullptr);
     void stop();                                                                                      // :204-208
     // :182-202 with URgbFormat::sRGB: H x W x 3 display values in [0,1]; the conversion runs on the device
     Result imageRGB(std::vector<double>& img_data, double gamma, size_t& img_width, size_t& img_height);

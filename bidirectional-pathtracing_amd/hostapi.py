@@ -15,7 +15,7 @@ UR_HEADER_BYTES = 68
 PROGRESS_CB = C.CFUNCTYPE(None, C.c_double)
 
 EXPORTS = ["uhip_engine_create", "uhip_engine_destroy", "uhip_engine_set_scene", "uhip_engine_new_rendering",
-           "uhip_engine_render_pass", "uhip_engine_render_passes", "uhip_engine_stop", "uhip_engine_curr_pass",
+           "uhip_engine_render_pass", "uhip_engine_render_passes", "uhip_engine_render_passes_progress", "uhip_engine_stop", "uhip_engine_curr_pass",
            "uhip_engine_sum", "uhip_engine_image_rgb", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write",
            "uhip_ur_read", "uhip_scene_load_xml", "uhip_scene_ok", "uhip_scene_error", "uhip_scene_desc",
            "uhip_scene_free", "uhip_multi_create", "uhip_multi_destroy", "uhip_multi_render_passes",
@@ -40,6 +40,7 @@ def load_library():
         lib.uhip_engine_new_rendering.argtypes = [vp, C.POINTER(capi.RenderParams), C.c_int]
         lib.uhip_engine_render_pass.argtypes = [vp, C.c_size_t, PROGRESS_CB]
         lib.uhip_engine_render_passes.argtypes = [vp, C.c_size_t]
+        lib.uhip_engine_render_passes_progress.argtypes = [vp, C.c_size_t, PROGRESS_CB]
         lib.uhip_engine_stop.restype = None
         lib.uhip_engine_stop.argtypes = [vp]
         lib.uhip_engine_curr_pass.restype = C.c_size_t
@@ -186,8 +187,10 @@ class Engine:
         cb = PROGRESS_CB(progress) if progress is not None else C.cast(None, PROGRESS_CB)
         return self.lib.uhip_engine_render_pass(self.h, num_threads, cb)
 
-    def render_passes(self, n):
-        return self.lib.uhip_engine_render_passes(self.h, n)
+    def render_passes(self, n, progress=None):
+        if progress is None:
+            return self.lib.uhip_engine_render_passes(self.h, n)
+        return self.lib.uhip_engine_render_passes_progress(self.h, n, PROGRESS_CB(progress))
 
     def stop(self):
         self.lib.uhip_engine_stop(self.h)

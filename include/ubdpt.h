@@ -240,6 +240,14 @@ int ubdpt_enqueue_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_pas
                          uint64_t pass_stride, uint64_t seed, uint32_t* passes_enqueued);
 int ubdpt_synchronize(ubdpt_context* ctx);
 
+/*
+ * The update_progress_callback of URenderer::renderPass (uengine/ubdptrenderer.cpp:54-62 counts finished pixels of
+ * the pass against W * H): pixel-samples handed to the GPU since ubdpt_create and how many of them the GPU has
+ * finished, without waiting for anything. A caller that enqueues passes polls it to drive a progress display.
+ * Either pointer may be NULL.
+ */
+int ubdpt_query_progress(ubdpt_context* ctx, uint64_t* samples_enqueued, uint64_t* samples_finished);
+
 /* URenderer::stop (uengine/ubdptrenderer.cpp:83-86): callable from any thread. */
 int ubdpt_request_stop(ubdpt_context* ctx);
 

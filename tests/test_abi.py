@@ -52,4 +52,5 @@ def test_argument_validation_needs_no_device():
     assert lib.ubdpt_create(None, None, None, 0, C.byref(h)) == capi.INVALID_ARG
     assert lib.ubdpt_destroy(None) == capi.INVALID_ARG
     assert lib.ubdpt_request_stop(None) == capi.INVALID_ARG
+    assert lib.ubdpt_query_progress(None, None, None) == capi.INVALID_ARG
     assert lib.ubdpt_read_sum(None, None, 0) == capi.INVALID_ARG

@@ -85,6 +85,40 @@ def test_engine_pass_by_pass_equals_batched_and_abi():
 
 
 @pytest.mark.gpu
+def test_progress_of_enqueued_passes():
+    """ubdpt_query_progress counts pixel-samples handed to the GPU and finished by it; HipEngine::renderPasses with a
+    callback reports the finished fraction of its passes (never decreasing, 1.0 at the end) and renders the same
+    image as without one."""
+    sc, params = c2(96, 96)
+    npix = 96 * 96
+    with capi.Context(sc, params) as ctx:
+        assert ctx.query_progress() == (0, 0)
+        ctx.enqueue_passes(0, 40, SEED)
+        enq, fin = ctx.query_progress()
+        assert enq == 40 * npix and 0 <= fin <= enq
+        ctx.synchronize()
+        assert ctx.query_progress() == (40 * npix, 40 * npix)
+        ctx.render_passes(40, 2, SEED)
+        assert ctx.query_progress() == (42 * npix, 42 * npix)
+        ref = ctx.read_sum()
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        seen = []
+        # more passes than one call of the engine enqueues (16 M pixel-samples), so the callback is heard in between
+        n = 2 * ((16 << 20) // npix) + 3
+        assert eng.render_passes(n, seen.append) == hostapi.USUCCESS and eng.curr_pass == n
+        assert len(seen) >= 3 and seen[-1] == 1.0
+        assert all(0.0 <= a <= b <= 1.0 for a, b in zip(seen, seen[1:]))
+        got = eng.sum()
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        assert eng.render_passes(42, lambda f: None) == hostapi.USUCCESS
+        b = eng.sum()
+    assert np.allclose(b, ref, rtol=1e-12, atol=1e-13)
+    assert np.isfinite(got).all() and got.sum() > 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pass_slots", [1, 4, 5])
 def test_engine_pass_by_pass_across_windows(pass_slots):
     """renderPass is served from windows of passes rendered ahead (two windows of pass_slots / 2 passes, one window of
