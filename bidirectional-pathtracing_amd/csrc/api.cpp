@@ -530,10 +530,14 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             if (pif > 64) pif = 64;
         }
         uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 16) : 2;
-        // the batch lanes together may take half of the memory that is free now (288 GB parts: ~140 GB)
+        // the batch lanes together may take four fifths of the memory that is free now (288 GB parts: ~230 GB, which holds
+        // batches of three 1080p passes per lane; with half of the memory, two passes per lane, the 2 M-triangle scene
+        // runs at 266 instead of 276 Mpaths/s). A second context on the same GPU gets four fifths of what is left, and
+        // so on: smaller batches, same results. UBDPT_MEM_FRACTION overrides the share.
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
-        const uint64_t lane_budget = std::max<uint64_t>(1ull << 30, (uint64_t)mem_free / 2 / nstreams);
+        static const double mem_fraction = [] { const char* e = getenv("UBDPT_MEM_FRACTION"); double f = e ? atof(e) : 0.8; return f > 0.05 && f <= 0.95 ? f : 0.8; }();
+        const uint64_t lane_budget = std::max<uint64_t>(1ull << 30, (uint64_t)((double)mem_free * mem_fraction) / nstreams);
         while (pif > 1 && (per_path + 1024) * c->npix * pif > lane_budget) pif--;
         // the packed queue entries hold a subpath id in 29 bits
         while (pif > 1 && 2 * c->npix * pif >= (1ull << 29) - 1) pif--;
