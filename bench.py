@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--accel", type=int, default=0)
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--passes-in-flight", type=int, default=0)
+    ap.add_argument("--max-path-vertices", type=int, default=0, help="cap on the vertices of a subpath (0 = the library's default, 32)")
     ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--batch-pixel-samples", type=int, default=0, help="sub-pass batches of this many pixels (0 = whole passes)")
@@ -322,6 +323,7 @@ def main():
     opt.accel = args.accel
     opt.pipeline = args.pipeline
     opt.passes_in_flight = args.passes_in_flight
+    opt.max_path_vertices = args.max_path_vertices
     opt.wavefront_depth = args.wavefront_depth
     opt.streams = args.streams
     opt.batch_pixel_samples = args.batch_pixel_samples
@@ -358,7 +360,7 @@ def main():
                        "triangles": int(scene.num_faces), "passes_per_step": pps, "spp_total": total_passes,
                        "passes_per_gpu": args.steps * pps,
                        "accel": "lbvh" if args.accel == 0 else "linear", "pipeline": args.pipeline,
-                       "passes_in_flight": args.passes_in_flight or "auto", "streams": args.streams or "default",
+                       "passes_in_flight": args.passes_in_flight or "auto", "max_path_vertices": args.max_path_vertices or 32, "streams": args.streams or "default",
                        "wavefront_depth": args.wavefront_depth or "default", "partition": f"passes round-robin over {ngpu} GPU(s)"},
             "timed_seconds": elapsed,
             "mrays_per_s": value * work["rays_per_pixel_sample"],

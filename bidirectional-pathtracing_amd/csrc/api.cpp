@@ -160,6 +160,11 @@ struct ubdpt_context {
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
     uint64_t paths_enqueued = 0;  // pixel-samples of all batches enqueued so far (ubdpt_query_progress)
+    // Passes of an ubdpt_enqueue_passes call that did not fill a batch (the call's passes modulo the passes of a batch):
+    // they are held back and start the next call's first batch when that call continues where this one ended; every
+    // other call, and everything that waits for the enqueued work, launches them first.
+    struct Held { uint64_t first = 0, stride = 1, seed = 0; uint32_t count = 0; } held;
+    bool flushing_held = false;   // held passes are being launched: the call that took them promised them, a stop request does not drop them
     bool work_pending = false;    // batches were enqueued and not yet waited for
     double pending_since = 0;
     unsigned long long* d_counters = nullptr;
@@ -634,8 +639,22 @@ static int reportStackOverflows(ubdpt_context* c) {
 
 // Waits for every enqueued batch, then folds the event timings and the device counters into the
 // statistics. Called with the context mutex held.
+static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                              uint32_t* passes_done, bool wait, bool separate, uint32_t first_slot, bool may_hold);
+// launches the passes a call held back (context mutex held)
+static int flushHeld(ubdpt_context* c) {
+    if (!c->held.count) return UBDPT_SUCCESS;
+    const ubdpt_context::Held h = c->held;
+    c->held.count = 0;
+    c->flushing_held = true;
+    const int st = renderPassesLocked(c, h.first, h.count, h.stride, h.seed, nullptr, false, false, 0, false);
+    c->flushing_held = false;
+    return st;
+}
+
 static int finishPending(ubdpt_context* c) {
     if (!c->work_pending) return UBDPT_SUCCESS;
+    { int fh = flushHeld(c); if (fh != UBDPT_SUCCESS) return fh; }
     for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
     c->work_pending = false;
     c->collectLanes();
@@ -655,6 +674,26 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
     std::lock_guard<std::mutex> lock(c->mu);
     HIPCK(c, hipSetDevice(c->device));
     c->stop = false;  // UBDPTRenderer::renderPass resets m_stop (ubdptrenderer.cpp:37)
+    return renderPassesLocked(c, first_pass, n_passes, pass_stride, seed, passes_done, wait, separate, first_slot, true);
+}
+
+static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes, uint64_t pass_stride, uint64_t seed,
+                              uint32_t* passes_done, bool wait, bool separate, uint32_t first_slot, bool may_hold) {
+    // passes an earlier call held back: this call takes them along when it continues where that call ended
+    uint32_t merged = 0;
+    if (c->held.count) {
+        const ubdpt_context::Held h = c->held;
+        if (may_hold && !separate && h.stride == pass_stride && h.seed == seed &&
+            first_pass == h.first + (uint64_t)h.count * h.stride && n_passes <= 0xffffffffu - h.count) {
+            c->held.count = 0;
+            first_pass = h.first;
+            n_passes += h.count;
+            merged = h.count;
+        } else {
+            int fh = flushHeld(c);
+            if (fh != UBDPT_SUCCESS) return fh;
+        }
+    }
     if (separate) {   // the per-pass buffers of this call start from zero
         if (wait) {
             int fs = finishPending(c);
@@ -682,10 +721,16 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
     uint64_t& batch = c->next_batch;
     // pixel-samples of this call in (pass, pixel) order; a batch is a contiguous range of them: whole passes, or
     // (when the batch size is below one pass) a range of pixels inside one pass
-    const uint64_t total_paths = (uint64_t)n_passes * c->npix;
+    // a call that is not waited for leaves the passes that do not fill a batch to the next call (see Held), provided
+    // it launches at least one batch itself, so that the device has work until then
+    uint32_t hold = 0;
+    if (may_hold && !wait && !separate && c->cap_paths >= c->npix && c->passes_in_flight > 1 && n_passes > c->passes_in_flight)
+        hold = n_passes % c->passes_in_flight;
+    const uint64_t total_paths = (uint64_t)(n_passes - hold) * c->npix;
     uint64_t pos = 0;
     while (pos < total_paths) {
-        if (pos % c->npix == 0 && c->stop.load()) { status = UBDPT_STOPPED; break; }
+        // (the passes taken over from an earlier call were promised by that call: a stop request does not drop them)
+        if (pos % c->npix == 0 && pos >= (uint64_t)merged * c->npix && !c->flushing_held && c->stop.load()) { status = UBDPT_STOPPED; break; }
         uint64_t nbatch = std::min<uint64_t>(c->cap_paths, total_paths - pos);
         if (c->cap_paths < c->npix) nbatch = std::min<uint64_t>(nbatch, c->npix - pos % c->npix);
         ubdpt_context::BatchLane& B = c->lanes[batch % c->lanes.size()];
@@ -778,7 +823,13 @@ static int renderPasses(ubdpt_context* c, uint64_t first_pass, uint32_t n_passes
     done = (uint32_t)(pos / c->npix);
     c->stats.passes += done;
     c->stats.pixel_samples += (uint64_t)done * c->npix;
-    if (passes_done) *passes_done = done;
+    if (hold && status == UBDPT_SUCCESS) {
+        c->held.first = first_pass + (uint64_t)(n_passes - hold) * pass_stride;
+        c->held.count = hold; c->held.stride = pass_stride; c->held.seed = seed;
+    } else
+        hold = 0;
+    // passes of THIS call that were launched or are held for the next one
+    if (passes_done) *passes_done = done + hold - merged;
     if (separate) {
         int fence = -1;
         if (!wait) {  // one event per lane behind the batches of this call
@@ -823,7 +874,8 @@ int ubdpt_query_progress(ubdpt_context* c, uint64_t* samples_enqueued, uint64_t*
         }
     }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error status
-    if (samples_enqueued) *samples_enqueued = c->paths_enqueued;
+    // passes held back for the next call count as enqueued: the call that took them reported them so
+    if (samples_enqueued) *samples_enqueued = c->paths_enqueued + (uint64_t)c->held.count * c->npix;
     if (samples_finished) *samples_finished = c->paths_enqueued - unfinished;
     return UBDPT_SUCCESS;
 }

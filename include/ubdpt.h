@@ -235,6 +235,9 @@ int ubdpt_image_rgb(ubdpt_context* ctx, uint64_t passes, double gamma, double* r
  * renderPass again as soon as the previous pass returned, uapp/appmanager.cpp:486).
  * Every entry point that reads results (read_sum*, get_stats, ...) waits for the enqueued passes
  * first; ubdpt_synchronize waits explicitly and reports errors of the enqueued work.
+ * The passes of a call that do not fill a batch are started together with the next call's passes when that call
+ * continues where this one ended (same seed and stride, next pass), otherwise before whatever comes next; they are
+ * counted in *passes_enqueued of the call that took them.
  */
 int ubdpt_enqueue_passes(ubdpt_context* ctx, uint64_t first_pass, uint32_t n_passes,
                          uint64_t pass_stride, uint64_t seed, uint32_t* passes_enqueued);

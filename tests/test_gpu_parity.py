@@ -506,6 +506,44 @@ def test_passes_in_flight_does_not_change_the_result(oracle_mod):
     a.close(); b.close()
 
 
+def test_passes_that_do_not_fill_a_batch_wait_for_the_next_call():
+    """An enqueue call leaves the passes that do not fill a batch to the next call when that call continues where it
+    ended, and launches them itself otherwise (another seed, a gap, a stride, a waited call, a read): whatever the
+    calls are cut into, every pass is rendered exactly once and reported by the call that took it."""
+    scene = SCENES["C2"]()
+    scene.desc.camera.ratio = 1.0
+    params = scenes.make_params(40, 40)
+    npix = 40 * 40
+    opt = capi.Options()
+    opt.passes_in_flight = 3
+    with capi.Context(scene, params, opt) as ctx:
+        ctx.render_passes(0, 25, SEED)
+        ref = ctx.read_sum()
+        ctx.upload_sum(None)
+        # 7 = 2 batches + 1 held; 4 (+1) = 1 batch + 2 held; 2 (+2) = 1 batch + 1 held; a gap: the held pass runs alone;
+        # 8 = 2 batches + 2 held; a waited call takes them along: (2 +) 3 = 1 batch + 2 more passes
+        done = [ctx.enqueue_passes(0, 7, SEED)[1], ctx.enqueue_passes(7, 4, SEED)[1], ctx.enqueue_passes(11, 2, SEED)[1]]
+        enq, fin = ctx.query_progress()
+        assert done == [7, 4, 2] and enq - 25 * npix == 13 * npix and fin <= enq
+        done.append(ctx.enqueue_passes(14, 8, SEED)[1])
+        st, d = ctx.render_passes(22, 3, SEED)
+        assert done[-1] == 8 and st == capi.SUCCESS and d == 3
+        ctx.render_passes(13, 1, SEED)            # the pass the gap left out
+        assert ctx.query_progress() == (50 * npix, 50 * npix)
+        got = ctx.read_sum()
+        assert ctx.stats()["passes"] == 50
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-12) and ref.sum() > 0
+        # passes held when another seed, a stride or a read comes: launched before it
+        ctx.upload_sum(None)
+        ctx.enqueue_passes(0, 4, SEED)            # 1 batch + 1 held
+        ctx.enqueue_passes(4, 5, SEED + 1)        # another seed: the held pass goes first; 1 batch + 2 held
+        ctx.enqueue_passes(9, 4, SEED + 1, pass_stride=2)   # another stride
+        mixed = ctx.read_sum()                    # waits for everything, held passes included
+        ctx.upload_sum(None)
+        ctx.render_passes(0, 4, SEED); ctx.render_passes(4, 5, SEED + 1); ctx.render_passes(9, 4, SEED + 1, pass_stride=2)
+        assert np.allclose(mixed, ctx.read_sum(), rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("pipeline", [0, 1])
 def test_sub_pass_batches_and_many_streams_do_not_change_the_result(pipeline):
     """Batches of a few thousand pixels of one pass (never across a pass boundary), spread over 5 streams,
