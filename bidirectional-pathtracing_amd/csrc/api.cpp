@@ -127,7 +127,8 @@ struct ubdpt_context {
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
     uint32_t passes_in_flight = 1;
     uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
-    uint64_t ovf_threads = 0;     // lanes the overflow-stack buffer is sized for
+    uint64_t ovf_threads = 0;     // path slots of a lane, rounded up to whole workgroups
+    uint64_t ovf_lanes = 0;       // lanes the overflow-stack buffer is allocated for (= its stride)
     uint32_t ovf_cap = kLdsStack + kOverflowStack;  // entries of a lane's whole traversal stack (on-chip part included)
     void* noalloc_scratch = nullptr;             // device address of the static scratch array on this context's GPU
     unsigned long long* h_noalloc_counters = nullptr;  // pinned, kNumCounters words: counters of the last no-allocation call
@@ -275,6 +276,9 @@ struct ubdpt_context {
 };
 
 namespace {
+
+constexpr uint64_t kQueuePerPath = 20;            // entries of the pair / ray / visible-pair queues per pixel-sample of a batch
+constexpr uint64_t kMaxGridLanes = 2048ull * 256;  // lanes of the largest grid a grid-stride kernel is launched with
 
 #define HIPCK(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->last_hip = e_; \
     fprintf(stderr, "ubdpt: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return UBDPT_HIP_ERROR; } } while (0)
@@ -524,9 +528,15 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if ((st = flattenAndUpload(c, scene)) != UBDPT_SUCCESS) break;
         c->npix = params->img_res_x * params->img_res_y;
         // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
-        // (vertex records of both subpaths, overflow stack, pair / ray / visible-pair queues of 24 entries per path)
-        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 4ull * kOverflowStack + 8 +
-                            24ull * (8 + 8 + 8 + sizeof(double) * kRayDoubles + 1);
+        // (per pixel-sample: vertex records and count words of both subpaths, pair / ray / visible-pair queues of
+        // kQueuePerPath entries, two carry and hit records, queue words; the per-path kernels of pipeline 1 also need an
+        // overflow stack per pixel-sample, the wavefront kernels one per lane of their largest grid)
+        const bool wavefront = c->opt.pipeline == 0;
+        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 8 +
+                            kQueuePerPath * (8 + 8 + 8 + sizeof(double) * kRayDoubles + 1) +
+                            2 * sizeof(double) * (kCarryDoubles + kHitDoubles) + 16 + (wavefront ? 0 : 4ull * kOverflowStack);
+        const uint64_t lane_fixed = wavefront ? 4ull * kOverflowStack * kMaxGridLanes : 0;
+        auto laneBytes = [&](uint32_t passes) { return (per_path + 64) * c->npix * passes + lane_fixed; };
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
             uint64_t target = 1ull << 22;  // measured: throughput still rises up to ~4 M pixel-samples per batch
@@ -543,11 +553,11 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
         static const double mem_fraction = [] { const char* e = getenv("UBDPT_MEM_FRACTION"); double f = e ? atof(e) : 0.8; return f > 0.05 && f <= 0.95 ? f : 0.8; }();
         const uint64_t lane_budget = std::max<uint64_t>(1ull << 30, (uint64_t)((double)mem_free * mem_fraction) / nstreams);
-        while (pif > 1 && (per_path + 1024) * c->npix * pif > lane_budget) pif--;
+        while (pif > 1 && laneBytes(pif) > lane_budget) pif--;
         // the packed queue entries hold a subpath id in 29 bits
         while (pif > 1 && 2 * c->npix * pif >= (1ull << 29) - 1) pif--;
         // one pass of a very large image may already exceed a lane's share: then a single lane gets the whole budget
-        if ((per_path + 1024) * c->npix * pif > lane_budget) nstreams = 1;
+        if (laneBytes(pif) > lane_budget) nstreams = 1;
         c->passes_in_flight = pif;
         c->cap_paths = c->npix * pif;
         // a batch smaller than one pass: a range of pixels of one pass (never across a pass boundary)
@@ -570,12 +580,13 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix * (1 + c->pass_slots), c->stream));
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
-        // pair / ray / visible-pair queues: 24 entries per pixel-sample (a box scene averages 6 to 10); pixel-samples
+        c->ovf_lanes = wavefront ? std::min<uint64_t>(c->ovf_threads, kMaxGridLanes) : c->ovf_threads;
+        // pair / ray / visible-pair queues: kQueuePerPath entries per pixel-sample (a box scene averages 6 to 10); pixel-samples
         // beyond the queue's end are finished by k_pair_overflow. UBDPT_PAIR_QUEUE_PER_PATH shrinks it for tests of that path.
         {
             const char* e = getenv("UBDPT_PAIR_QUEUE_PER_PATH");
-            const unsigned long long per_path_entries = e && atoi(e) > 0 ? (unsigned long long)atoi(e) : 24ull;
-            c->pair_capacity = c->cap_paths * std::min(per_path_entries, 24ull);
+            const unsigned long long per_path_entries = e && atoi(e) > 0 ? (unsigned long long)atoi(e) : kQueuePerPath;
+            c->pair_capacity = c->cap_paths * std::min<unsigned long long>(per_path_entries, kQueuePerPath);
         }
         c->lanes.resize(nstreams);
         for (auto& b : c->lanes) {
@@ -584,7 +595,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             if ((st = allocStore(c, b.E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
             if ((st = allocStore(c, b.L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
             uint64_t n2 = 2 * c->cap_paths;
-            ck(hipMalloc((void**)&b.d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_threads));
+            ck(hipMalloc((void**)&b.d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_lanes));
             ck(hipMalloc((void**)&b.d_pairs, sizeof(uint64_t) * c->pair_capacity));
             ck(hipMalloc((void**)&b.d_pair_count, sizeof(unsigned long long)));
             ck(hipMalloc((void**)&b.d_carry, sizeof(double) * kCarryDoubles * n2));
@@ -761,13 +772,13 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
         double units = (double)A.E.n;
         // grid-stride kernels: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers;
         // 512 .. 16384 workgroups measured within 2 % of each other
-        unsigned pblocks = (unsigned)std::min<uint64_t>(2048, c->ovf_threads / 256);
+        unsigned pblocks = (unsigned)std::min<uint64_t>(kMaxGridLanes / 256, c->ovf_threads / 256);
         // the two persistent ray tracing kernels: what the GPU holds at once (256 CUs x 4 workgroups of 4 waves). A
         // larger grid only queues workgroups that find the ray queue empty; measured on the 2 M-triangle scene:
         // 2048 workgroups 234, 1024: 239, 768: 231, 512: 225 Mpaths/s. UBDPT_TRACE_BLOCKS overrides it for measurements.
         static const unsigned tblocks_env = [] { const char* e = getenv("UBDPT_TRACE_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
         const unsigned tblocks = std::min(tblocks_env ? tblocks_env : 1024u, pblocks);
-        uint64_t pstride = (uint64_t)pblocks * 256 > A.E.n ? (uint64_t)pblocks * 256 : A.E.n;
+        const uint64_t pstride = c->ovf_lanes;  // the wavefront kernels' grids have at most pblocks * 256 lanes
         // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, setup, rays, compact, eval (default)
         //           1 = per-path subpath kernels + per-path connection loop (the reference's loop structure, kept as a cross-check)
         const uint32_t pl = c->opt.pipeline;
@@ -1164,7 +1175,7 @@ int ubdpt_connection_probe(ubdpt_context* c, const ubdpt_path_vertex* eye, uint3
     hipError_t e = hipMemcpyAsync(d_eye, eye, sizeof(ubdpt_path_vertex) * n_eye, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_light, light, sizeof(ubdpt_path_vertex) * n_light, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        launchConnectionProbe(c->S, d_eye, n_eye, d_light, n_light, E, L, d_out, d_s0, c->lanes[0].d_ovf, c->ovf_threads,
+        launchConnectionProbe(c->S, d_eye, n_eye, d_light, n_light, E, L, d_out, d_s0, c->lanes[0].d_ovf, c->ovf_lanes,
                               c->ovf_cap, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
         e = hipGetLastError();
     }
