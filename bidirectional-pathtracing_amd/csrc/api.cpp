@@ -539,15 +539,19 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         auto laneBytes = [&](uint32_t passes) { return (per_path + 64) * c->npix * passes + lane_fixed; };
         uint32_t pif = c->opt.passes_in_flight;
         if (pif == 0) {
-            uint64_t target = 1ull << 22;  // measured: throughput still rises up to ~4 M pixel-samples per batch
+            // measured: a scene whose tree sits in LDS runs the same from 4 M pixel-samples per batch up (512 x 512 box,
+            // 16 to 32 passes); a scene in HBM gains with every pass the memory holds (2 M triangles at 1080p: 2 / 3 / 4
+            // passes per batch 266 / 279 / 286 Mpaths/s), because every launch of its ray tracing kernels ends with the
+            // drain of its longest rays
+            uint64_t target = sceneLdsLevel(c->S) == 2 ? 1ull << 22 : 1ull << 23;
             pif = (uint32_t)((target + c->npix - 1) / c->npix);
             if (pif < 1) pif = 1;
             if (pif > 64) pif = 64;
         }
         uint32_t nstreams = c->opt.streams ? std::min<uint32_t>(c->opt.streams, 16) : 2;
         // the batch lanes together may take four fifths of the memory that is free now (288 GB parts: ~230 GB, which holds
-        // batches of three 1080p passes per lane; with half of the memory, two passes per lane, the 2 M-triangle scene
-        // runs at 266 instead of 276 Mpaths/s). A second context on the same GPU gets four fifths of what is left, and
+        // batches of four 1080p passes per lane; with half of the memory, two passes per lane, the 2 M-triangle scene
+        // runs at 266 instead of 286 Mpaths/s). A second context on the same GPU gets four fifths of what is left, and
         // so on: smaller batches, same results. UBDPT_MEM_FRACTION overrides the share.
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
