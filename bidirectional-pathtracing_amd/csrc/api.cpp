@@ -263,6 +263,11 @@ struct ubdpt_context {
         hipFree(d_textures); hipFree(d_texels); hipFree(d_nodes); hipFree(d_xnodes); hipFree(d_prims); hipFree(d_fb); hipFree(d_staging);
         if (h_staging) { hipHostFree(h_staging); h_staging = nullptr; }
         if (h_noalloc_counters) { hipHostFree(h_noalloc_counters); h_noalloc_counters = nullptr; }
+        freeLanes();
+        hipFree(d_counters);
+        if (stream) hipStreamDestroy(stream);
+    }
+    void freeLanes() {
         for (auto& b : lanes) {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
@@ -270,8 +275,7 @@ struct ubdpt_context {
             hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_ray_pairs); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
         }
-        hipFree(d_counters);
-        if (stream) hipStreamDestroy(stream);
+        lanes.clear();
     }
 };
 
@@ -583,6 +587,9 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         ck(hipMalloc((void**)&c->d_staging, sizeof(double) * 3 * c->npix));
         if (st != UBDPT_SUCCESS) break;
         ck(hipMemsetAsync(c->d_fb, 0, sizeof(double) * 3 * c->npix * (1 + c->pass_slots), c->stream));
+        // The lanes' buffers. hipMemGetInfo above is a snapshot: when another process took memory in between, the
+        // allocation is tried again with batches of half the passes, then with one lane.
+        for (int attempt = 0;; attempt++) {
         c->ovf_threads = ((c->cap_paths + 255) / 256) * 256;
         c->ovf_lanes = wavefront ? std::min<uint64_t>(c->ovf_threads, kMaxGridLanes) : c->ovf_threads;
         // pair / ray / visible-pair queues: kQueuePerPath entries per pixel-sample (a box scene averages 6 to 10); pixel-samples
@@ -614,6 +621,19 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             }
             ck(hipMalloc((void**)&b.d_wf_trace_q, sizeof(uint32_t) * 2 * n2));
             ck(hipMalloc((void**)&b.d_wf_count, sizeof(uint32_t) * kWfQStride * (kMaxWfDepth + 2)));
+            if (st != UBDPT_SUCCESS) break;
+        }
+        if (st == UBDPT_SUCCESS) break;
+        const bool can_shrink = c->cap_paths >= c->npix && (c->passes_in_flight > 1 || nstreams > 1);
+        if (c->last_hip != hipErrorOutOfMemory || !can_shrink || attempt >= 8) break;
+        c->freeLanes();
+        (void)hipGetLastError();
+        st = UBDPT_SUCCESS;
+        if (c->passes_in_flight > 1) {
+            c->passes_in_flight = (c->passes_in_flight + 1) / 2;
+            c->cap_paths = c->npix * c->passes_in_flight;
+        } else
+            nstreams = 1;
         }
         if (st != UBDPT_SUCCESS) break;
         // set-up of the entry point that allocates nothing: this GPU's address of the static scratch array (asked for with
