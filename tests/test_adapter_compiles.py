@@ -25,7 +25,7 @@ def test_adapter_compiles_against_the_reference_interface():
 
 
 def test_integration_notes_show_the_adapter_that_is_checked():
-    """INTEGRATION.md quotes the adapter; the quoted class body must be the checked file's."""
+    """The integration guide at the repository root quotes the adapter; the quoted class body must be the checked file's."""
     src = open(os.path.join(ROOT, "bidirectional-pathtracing_amd", "host", "reference_adapter", "ubdpthiprenderer.h")).read()
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     body = src[src.index("class UBDPTHipRenderer"):src.index("#endif // UBDPTHIPRENDERER_H")].strip()
