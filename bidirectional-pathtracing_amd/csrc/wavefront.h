@@ -296,8 +296,11 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
 }
 
 // ---- tail: survivors of the last wavefront bounce finish in a per-lane loop ---------------------------
+#ifndef UBDPT_TAIL_WAVES
+#define UBDPT_TAIL_WAVES 2
+#endif
 template <bool STATS, int LDS_LEVEL>
-__global__ __launch_bounds__(kBlock, 2) void k_wf_tail(RenderArgs A0, uint32_t depth) {
+__global__ __launch_bounds__(kBlock, UBDPT_TAIL_WAVES) void k_wf_tail(RenderArgs A0, uint32_t depth) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     __shared__ DObject s_objects[ldsObjects(LDS_LEVEL)];
     __shared__ LdsNode s_nodes[ldsNodes(LDS_LEVEL)];
