@@ -899,6 +899,7 @@ int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passe
 int ubdpt_query_progress(ubdpt_context* c, uint64_t* samples_enqueued, uint64_t* samples_finished) {
     if (!c) return UBDPT_INVALID_ARG;
     std::lock_guard<std::mutex> lock(c->mu);
+    HIPCK(c, hipSetDevice(c->device));
     uint64_t unfinished = 0;
     for (auto& b : c->lanes) {
         // a lane's batches finish in order: everything from the first marker that has not been reached is unfinished
