@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """PCIe-inclusive rate of the reference-shaped interface: HipEngine::renderPass hands a HOST sum
 buffer to the renderer every pass (device clear, one pass, read-back, add on the host), against
-HipEngine::renderPasses, which keeps the sum on the device: python tools/host_pass_rate.py [config, default C2]."""
+HipEngine::renderPasses, which keeps the sum on the device: python tools/host_pass_rate.py [config, default C2] [pass_slots]."""
 import importlib
 import os
 import sys
@@ -15,12 +15,16 @@ hostapi = importlib.import_module("bidirectional-pathtracing_amd.hostapi")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 sc, params, _ = pkg.scenes.make_config(cfg)
 npix = int(params.img_res_x * params.img_res_y)
-with hostapi.Engine(sc) as eng:
+opt = None
+if len(sys.argv) > 2:  # per-pass buffers of the engine's renderer (two windows of half as many passes)
+    opt = pkg.capi.Options()
+    opt.pass_slots = int(sys.argv[2])
+with hostapi.Engine(sc, options=opt) as eng:
     assert eng.new_rendering(params) == 0
-    for _ in range(4):
+    for _ in range(4 if opt is None else max(4, opt.pass_slots)):
         eng.render_pass()
     t = time.perf_counter()
-    n = 32 if npix < (1 << 20) else 12
+    n = 32 if npix < (1 << 20) else 24
     for _ in range(n):
         assert eng.render_pass() == 0
     dt = time.perf_counter() - t
