@@ -160,7 +160,11 @@ struct ubdpt_context {
     };
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
-    uint64_t paths_enqueued = 0;  // pixel-samples of all batches enqueued so far (ubdpt_query_progress)
+    // ubdpt_query_progress reads these without the context mutex (an enqueue call holds that one while it waits for room on
+    // the device): the counts are atomics, and the lanes' marker lists are changed and read under progress_mu only
+    std::atomic<uint64_t> paths_enqueued{0};  // pixel-samples of all batches enqueued so far
+    std::atomic<uint64_t> paths_held{0};      // pixel-samples of the passes held back for the next call
+    std::mutex progress_mu;
     // Passes of an ubdpt_enqueue_passes call that did not fill a batch (the call's passes modulo the passes of a batch):
     // they are held back and start the next call's first batch when that call continues where this one ended; every
     // other call, and everything that waits for the enqueued work, launches them first.
@@ -222,6 +226,7 @@ struct ubdpt_context {
         if (!marker_pool.empty()) { ev = marker_pool.back(); marker_pool.pop_back(); }
         else hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         hipEventRecord(ev, b.stream);
+        std::lock_guard<std::mutex> pl(progress_mu);
         b.inflight.push_back(BatchLane::Marker{ev, b.pending.size(), paths});
         paths_enqueued += paths;
     }
@@ -232,6 +237,7 @@ struct ubdpt_context {
             hipError_t e = hipEventSynchronize(front.first);
             if (e != hipSuccess) return e;
             foldTimed(b.pending, front.second);
+            std::lock_guard<std::mutex> pl(progress_mu);
             b.inflight.pop_front();
             for (auto& f : b.inflight) f.second -= front.second;
             marker_pool.push_back(front.first);
@@ -242,6 +248,7 @@ struct ubdpt_context {
     void collectLanes() {
         for (auto& b : lanes) {
             foldTimed(b.pending, b.pending.size());
+            std::lock_guard<std::mutex> pl(progress_mu);
             for (auto& f : b.inflight) marker_pool.push_back(f.first);
             b.inflight.clear();
         }
@@ -457,15 +464,15 @@ int fetchCounters(ubdpt_context* c) {
     for (int k = 0; k < K_NUM; k++) {
         const unsigned long long* h = hk[k];
         for (int j = 0; j < kNumCounters; j++) {
-            if (j == 13) c->kernel_counters[k][j] = std::max(c->kernel_counters[k][j], h[j]);  // C_MAX_STACK is a maximum
+            if (j == C_MAX_STACK) c->kernel_counters[k][j] = std::max(c->kernel_counters[k][j], h[j]);
             else c->kernel_counters[k][j] += h[j];
         }
         if (k <= kLastRenderKernel) {  // the probe kernels do not count as rendering work
-            c->stats.closest_hit_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.eye_vertices += h[2];
-            c->stats.light_vertices += h[3]; c->stats.connections += h[4]; c->stats.splats += h[5];
-            c->stats.bvh_nodes_visited += h[6]; c->stats.prims_tested += h[7]; c->stats.capped_subpaths += h[8];
+            c->stats.closest_hit_rays += h[C_CLOSEST]; c->stats.shadow_rays += h[C_SHADOW]; c->stats.eye_vertices += h[C_EYE_V];
+            c->stats.light_vertices += h[C_LIGHT_V]; c->stats.connections += h[C_CONN]; c->stats.splats += h[C_SPLAT];
+            c->stats.bvh_nodes_visited += h[C_NODES]; c->stats.prims_tested += h[C_PRIMS]; c->stats.capped_subpaths += h[C_CAPPED];
         }
-        c->stack_overflows += h[9];
+        c->stack_overflows += h[C_STACK_OVERFLOW];
     }
     return UBDPT_SUCCESS;
 }
@@ -680,7 +687,7 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
 static int flushHeld(ubdpt_context* c) {
     if (!c->held.count) return UBDPT_SUCCESS;
     const ubdpt_context::Held h = c->held;
-    c->held.count = 0;
+    c->held.count = 0; c->paths_held = 0;
     c->flushing_held = true;
     const int st = renderPassesLocked(c, h.first, h.count, h.stride, h.seed, nullptr, false, false, 0, false);
     c->flushing_held = false;
@@ -720,7 +727,7 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
         const ubdpt_context::Held h = c->held;
         if (may_hold && !separate && h.stride == pass_stride && h.seed == seed &&
             first_pass == h.first + (uint64_t)h.count * h.stride && n_passes <= 0xffffffffu - h.count) {
-            c->held.count = 0;
+            c->held.count = 0; c->paths_held = 0;
             first_pass = h.first;
             n_passes += h.count;
             merged = h.count;
@@ -861,6 +868,7 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
     if (hold && status == UBDPT_SUCCESS) {
         c->held.first = first_pass + (uint64_t)(n_passes - hold) * pass_stride;
         c->held.count = hold; c->held.stride = pass_stride; c->held.seed = seed;
+        c->paths_held = (uint64_t)hold * c->npix;
     } else
         hold = 0;
     // passes of THIS call that were launched or are held for the next one
@@ -898,8 +906,10 @@ int ubdpt_enqueue_passes(ubdpt_context* c, uint64_t first_pass, uint32_t n_passe
 
 int ubdpt_query_progress(ubdpt_context* c, uint64_t* samples_enqueued, uint64_t* samples_finished) {
     if (!c) return UBDPT_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(c->mu);
-    HIPCK(c, hipSetDevice(c->device));
+    // not the context mutex: an enqueue call holds it while it waits for room on the device, and a thread that polls
+    // the progress must not wait with it
+    std::lock_guard<std::mutex> lock(c->progress_mu);
+    if (hipSetDevice(c->device) != hipSuccess) return UBDPT_HIP_ERROR;
     uint64_t unfinished = 0;
     for (auto& b : c->lanes) {
         // a lane's batches finish in order: everything from the first marker that has not been reached is unfinished
@@ -911,8 +921,9 @@ int ubdpt_query_progress(ubdpt_context* c, uint64_t* samples_enqueued, uint64_t*
     }
     (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error status
     // passes held back for the next call count as enqueued: the call that took them reported them so
-    if (samples_enqueued) *samples_enqueued = c->paths_enqueued + (uint64_t)c->held.count * c->npix;
-    if (samples_finished) *samples_finished = c->paths_enqueued - unfinished;
+    const uint64_t enq = c->paths_enqueued.load();
+    if (samples_enqueued) *samples_enqueued = enq + c->paths_held.load();
+    if (samples_finished) *samples_finished = enq - unfinished;
     return UBDPT_SUCCESS;
 }
 
@@ -1105,7 +1116,7 @@ int ubdpt_intersect_batch(ubdpt_context* c, const ubdpt_ray* rays, size_t n, ubd
         hipError_t e = hipMemcpyAsync(d_rays, rays + off, sizeof(ubdpt_ray) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_INTERSECT, (double)k);
-            launchIntersectBatch(c->S, d_rays, k, d_hits, c->lanes[0].d_ovf, k, c->ovf_cap, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
+            launchIntersectBatch(c->S, d_rays, k, d_hits, c->lanes[0].d_ovf, c->ovf_lanes, c->ovf_cap, c->d_counters + K_INTERSECT * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -1135,7 +1146,7 @@ int ubdpt_intersect_batch_noalloc(ubdpt_context* c, const ubdpt_ray* device_rays
     HIPCK(c, launchIntersectBatchNoAlloc(c->S, device_rays, n, device_hits, c->noalloc_scratch, c->ovf_cap,
                                          c->h_noalloc_counters, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
-    if (c->h_noalloc_counters[9]) {  // C_STACK_OVERFLOW
+    if (c->h_noalloc_counters[C_STACK_OVERFLOW]) {
         fprintf(stderr, "ubdpt_intersect_batch_noalloc: traversal stack overflow; the result of this call is not valid\n");
         return UBDPT_ERROR;
     }
@@ -1160,7 +1171,7 @@ int ubdpt_visibility_batch(ubdpt_context* c, const ubdpt_segment* segs, size_t n
         hipError_t e = hipMemcpyAsync(d_segs, segs + off, sizeof(ubdpt_segment) * k, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) {
             c->beginTimed(K_VISIBILITY, (double)k);
-            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->lanes[0].d_ovf, k, c->ovf_cap, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
+            launchVisibilityBatch(c->S, d_segs, k, d_vis, c->lanes[0].d_ovf, c->ovf_lanes, c->ovf_cap, c->d_counters + K_VISIBILITY * kNumCounters, c->stream);
             c->endTimed();
             e = hipGetLastError();
         }
@@ -1275,9 +1286,9 @@ int ubdpt_get_stats(ubdpt_context* c, ubdpt_stats* out) {
         snprintf(ks.name, sizeof(ks.name), "%s", kKernelNames[k]);
         ks.launches = c->kernel_launches[k]; ks.ms = c->kernel_ms[k]; ks.units = c->kernel_units[k];
         const unsigned long long* h = c->kernel_counters[k];
-        ks.closest_hit_rays = h[0]; ks.shadow_rays = h[1]; ks.nodes_visited = h[6]; ks.prims_tested = h[7];
-        ks.wave_node_steps = h[11]; ks.wave_prim_steps = h[12]; ks.max_stack_entries = h[13];
-        ks.vertices = h[2] + h[3]; ks.fb_updates = h[10];
+        ks.closest_hit_rays = h[C_CLOSEST]; ks.shadow_rays = h[C_SHADOW]; ks.nodes_visited = h[C_NODES]; ks.prims_tested = h[C_PRIMS];
+        ks.wave_node_steps = h[C_WAVE_NODES]; ks.wave_prim_steps = h[C_WAVE_PRIMS]; ks.max_stack_entries = h[C_MAX_STACK];
+        ks.vertices = h[C_EYE_V] + h[C_LIGHT_V]; ks.fb_updates = h[C_FB];
     }
     return UBDPT_SUCCESS;
 }

@@ -61,6 +61,10 @@ void launchPairCompact(const RenderArgs& A, unsigned blocks, hipStream_t s);
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s);
 
 constexpr int kNumCounters = 16;
+// counters, indices into RenderArgs::counters (one block of kNumCounters words per kernel); C_MAX_STACK is a maximum, the others are sums
+enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB,
+       C_WAVE_NODES, C_WAVE_PRIMS, C_MAX_STACK, C_NUM };
+static_assert(C_NUM <= kNumCounters, "counter block too small");
 
 void launchEye(const RenderArgs& A, bool stats, hipStream_t s);
 void launchLight(const RenderArgs& A, bool stats, hipStream_t s);

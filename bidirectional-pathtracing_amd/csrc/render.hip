@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "paths.h"
 #include "render.h"
@@ -15,10 +16,6 @@ namespace ub {
 
 constexpr int kBlock = 256;
 
-// counters, indices into RenderArgs::counters
-enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB,
-       C_WAVE_NODES, C_WAVE_PRIMS, C_MAX_STACK, C_NUM };
-static_assert(C_NUM <= kNumCounters, "counter block too small");
 
 struct Tally {
     uint32_t closest = 0, shadow = 0, conn = 0, splat = 0, capped = 0, fb = 0;
@@ -729,15 +726,17 @@ __global__ __launch_bounds__(kBlock) void k_visibility_batch(DScene S, const ubd
                                                             uint8_t* vis, int32_t* ovf, uint64_t ovf_stride, uint32_t ovf_cap,
                                                             unsigned long long* counters) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (gid >= n) return;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t lanes = (uint64_t)gridDim.x * kBlock;
     Stack st = makeStack(lds_stack, ovf, ovf_stride, gid, ovf_cap);
     Tally ty;
-    d3 p0 = mk3(segs[gid].p0[0], segs[gid].p0[1], segs[gid].p0[2]);
-    d3 p1 = mk3(segs[gid].p1[0], segs[gid].p1[1], segs[gid].p1[2]);
-    vis[gid] = visible<true>(S, p0, p1, st, ty) ? 1 : 0;
-    atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
-    atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
+    for (uint64_t i = gid; i < n; i += lanes) {
+        d3 p0 = mk3(segs[i].p0[0], segs[i].p0[1], segs[i].p0[2]);
+        d3 p1 = mk3(segs[i].p1[0], segs[i].p1[1], segs[i].p1[2]);
+        vis[i] = visible<true>(S, p0, p1, st, ty) ? 1 : 0;
+    }
+    if (ty.tc.nodes) atomicAdd(&counters[C_NODES], (unsigned long long)ty.tc.nodes);
+    if (ty.tc.prims) atomicAdd(&counters[C_PRIMS], (unsigned long long)ty.tc.prims);
     if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
 }
 
@@ -769,10 +768,13 @@ __global__ __launch_bounds__(kBlock) void k_connection_probe(DScene S, PathStore
                                                             ubdpt_connection* out, double* s0, int32_t* ovf, uint64_t ovf_stride,
                                                             uint32_t ovf_cap, unsigned long long* counters) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
-    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    Stack st = makeStack(lds_stack, ovf, ovf_stride, gid, ovf_cap);
+    const uint64_t lane0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t lanes = (uint64_t)gridDim.x * kBlock;
+    Stack st = makeStack(lds_stack, ovf, ovf_stride, lane0, ovf_cap);
     Tally ty;
     const uint32_t pairs = n_eye * n_light;
+    const uint64_t work = (uint64_t)pairs + n_eye;
+    for (uint64_t gid = lane0; gid < work; gid += lanes) {
     if (gid < pairs) {
         const uint32_t s = (uint32_t)gid / n_eye + 1, t = (uint32_t)gid % n_eye + 1;
         ubdpt_connection o;
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void k_connection_probe(DScene S, PathStore
             }
         }
         out[gid] = o;
-    } else if (s0 && gid - pairs < n_eye) {
+    } else if (s0) {
         const uint32_t t = (uint32_t)(gid - pairs);
         d3 v = mk3(0, 0, 0);
         if (t >= 1) {
@@ -806,6 +808,7 @@ __global__ __launch_bounds__(kBlock) void k_connection_probe(DScene S, PathStore
             v = s0sample(S, E, 0, t, cur, prev_specular, ev);
         }
         s0[3 * t] = v.x; s0[3 * t + 1] = v.y; s0[3 * t + 2] = v.z;
+    }
     }
     if (st.overflowed) atomicAdd(&counters[C_STACK_OVERFLOW], 1ULL);
 }
@@ -990,12 +993,15 @@ void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_intersect_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, rays, n, hits, ovf, ovf_stride, ovf_cap, counters);
+    // grid-stride: never more lanes than the overflow buffer has slices (ovf_stride, a multiple of the workgroup size)
+    const unsigned blocks = (unsigned)std::min<uint64_t>(gridFor(n), std::max<uint64_t>(1, ovf_stride / kBlock));
+    hipLaunchKernelGGL(k_intersect_batch, dim3(blocks), dim3(kBlock), 0, s, S, rays, n, hits, ovf, ovf_stride, ovf_cap, counters);
 }
 void launchVisibilityBatch(const DScene& S, const ubdpt_segment* segs, size_t n, uint8_t* vis, int32_t* ovf,
                            uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_visibility_batch, dim3(gridFor(n)), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, ovf_cap, counters);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(gridFor(n), std::max<uint64_t>(1, ovf_stride / kBlock));
+    hipLaunchKernelGGL(k_visibility_batch, dim3(blocks), dim3(kBlock), 0, s, S, segs, n, vis, ovf, ovf_stride, ovf_cap, counters);
 }
 void launchConnectionProbe(const DScene& S, const ubdpt_path_vertex* eye, uint32_t n_eye, const ubdpt_path_vertex* light,
                            uint32_t n_light, PathStore E, PathStore L, ubdpt_connection* out, double* s0, int32_t* ovf,
@@ -1003,7 +1009,8 @@ void launchConnectionProbe(const DScene& S, const ubdpt_path_vertex* eye, uint32
     hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(kBlock), 0, s, S, eye, n_eye, E);
     hipLaunchKernelGGL(k_probe_fill, dim3(1), dim3(kBlock), 0, s, S, light, n_light, L);
     const uint64_t threads = (uint64_t)n_eye * n_light + n_eye;
-    hipLaunchKernelGGL(k_connection_probe, dim3(gridFor(threads)), dim3(kBlock), 0, s, S, E, L, n_eye, n_light, out, s0, ovf,
+    const unsigned blocks = (unsigned)std::min<uint64_t>(gridFor(threads), std::max<uint64_t>(1, ovf_stride / kBlock));
+    hipLaunchKernelGGL(k_connection_probe, dim3(blocks), dim3(kBlock), 0, s, S, E, L, n_eye, n_light, out, s0, ovf,
                        ovf_stride, ovf_cap, counters);
 }
 void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_result* r, hipStream_t s) {
@@ -1037,10 +1044,12 @@ static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
 
 constexpr int kMaxScratchDevices = 64;
 static void* g_scratch_ptr[kMaxScratchDevices] = {nullptr};
+static std::mutex g_scratch_mu;  // contexts may be created from several threads at once
 
 hipError_t noAllocScratch(int device, void** out) {
     *out = nullptr;
     if (device < 0 || device >= kMaxScratchDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
     if (!g_scratch_ptr[device]) {
         int cur = -1;
         hipError_t e = hipGetDevice(&cur);

@@ -9,10 +9,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <new>
 #include <sstream>
 
 namespace uhip {
 namespace formats {
+
+// largest image a reader accepts (2^28 pixels = 1 GiB of RGBA8): header fields beyond it are taken for damage
+constexpr uint64_t kMaxImagePixels = 1ull << 28;
 
 namespace {
 
@@ -333,7 +337,7 @@ bool loadPng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vecto
         else if (!std::memcmp(type, "IEND", 4)) break;
         p += 12 + (size_t)len;
     }
-    if (!seen_ihdr || W == 0 || H == 0 || W > (1u << 16) || H > (1u << 16)) return false;
+    if (!seen_ihdr || W == 0 || H == 0 || W > (1u << 16) || H > (1u << 16) || (uint64_t)W * H > kMaxImagePixels) return false;
     int channels;
     switch (ctype) {
         case 0: channels = 1; break;
@@ -362,6 +366,8 @@ bool loadPng(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vecto
         const size_t ph = (H > passes[k].y0) ? (H - passes[k].y0 + passes[k].dy - 1) / passes[k].dy : 0;
         if (pw && ph) raw_size += ph * (rowBytes(pw) + 1);
     }
+    // deflate expands by at most 1032 : 1, so a header that promises more than the compressed data can hold is damaged
+    if (idat.empty() || raw_size / 1032 > idat.size()) return false;
     std::vector<uint8_t> raw(raw_size);
     uLongf got = (uLongf)raw_size;
     if (idat.empty() || uncompress(raw.data(), &got, idat.data(), (uLong)idat.size()) != Z_OK || got != raw_size) return false;
@@ -422,7 +428,7 @@ bool loadBmp(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vecto
     uint32_t ncol = le32(f.data() + 46);
     const bool top_down = Hs < 0;
     const int64_t H = top_down ? -(int64_t)Hs : Hs;
-    if (W <= 0 || H <= 0 || W > (1 << 16) || H > (1 << 16)) return false;
+    if (W <= 0 || H <= 0 || W > (1 << 16) || H > (1 << 16) || (uint64_t)W * (uint64_t)H > kMaxImagePixels) return false;
     if (!(bpp == 1 || bpp == 4 || bpp == 8 || bpp == 24 || bpp == 32)) return false;
     if (!(comp == 0 || (comp == 3 && bpp == 32))) return false;
     uint32_t mask[3] = {0x00ff0000u, 0x0000ff00u, 0x000000ffu};
@@ -476,8 +482,13 @@ bool loadTga(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vecto
     const bool grey = type == 3 || type == 11, rle = type >= 10;
     if (!(grey ? bpp == 8 : (bpp == 24 || bpp == 32))) return false;
     const size_t px = bpp / 8;
-    std::vector<uint8_t> pix((size_t)W * H * px);
     size_t p = 18 + (size_t)idlen, o = 0;
+    // before anything is sized from the header: the pixel data must be able to come out of what the file holds (a
+    // run-length packet of 1 + px bytes makes at most 128 pixels)
+    if (p >= f.size() || (uint64_t)W * H > kMaxImagePixels) return false;
+    const uint64_t avail = f.size() - p;
+    if (rle ? ((uint64_t)W * H + 127) / 128 * (1 + px) > avail + px : (uint64_t)W * H * px > avail) return false;
+    std::vector<uint8_t> pix((size_t)W * H * px);
     if (!rle) {
         if (p + pix.size() > f.size()) return false;
         std::memcpy(pix.data(), f.data() + p, pix.size());
@@ -513,12 +524,19 @@ bool loadTga(const std::vector<uint8_t>& f, uint32_t& w, uint32_t& h, std::vecto
 }  // namespace
 
 bool loadImageFile(const std::string& path, uint32_t& w, uint32_t& h, std::vector<uint8_t>& rgba) {
-    std::vector<uint8_t> f;
-    if (!readFile(path, f) || f.size() < 4) return false;
-    if (f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G') return loadPng(f, w, h, rgba);
-    if (f[0] == 'B' && f[1] == 'M') return loadBmp(f, w, h, rgba);
-    if (lowerExtension(path) == "tga") return loadTga(f, w, h, rgba);
-    return false;
+    // a file that cannot be read is a texture that fails to load (as QImage::load does for the reference,
+    // uapp/textureimg.cpp:7-17), never an exception that leaves through the C entry points
+    try {
+        std::vector<uint8_t> f;
+        if (!readFile(path, f) || f.size() < 4) return false;
+        if (f[0] == 0x89 && f[1] == 'P' && f[2] == 'N' && f[3] == 'G') return loadPng(f, w, h, rgba);
+        if (f[0] == 'B' && f[1] == 'M') return loadBmp(f, w, h, rgba);
+        if (lowerExtension(path) == "tga") return loadTga(f, w, h, rgba);
+        return false;
+    } catch (const std::bad_alloc&) {
+        rgba.clear();
+        return false;
+    }
 }
 
 }  // namespace formats

@@ -98,12 +98,14 @@ bool HipRenderer::renderPassesOnDevice(size_t first_pass, size_t n, size_t* done
     if (done_out) *done_out = 0;
     if (!m_ctx) { m_status = UBDPT_UNINITIALIZED; return false; }
     size_t done_total = 0;
+    m_stop_requested = false;  // as renderPass: a stop request refers to the call it arrives in
     if (!progress || !*progress) {
         while (done_total < n) {
             uint32_t chunk = (uint32_t)std::min<size_t>(n - done_total, 1u << 20), done = 0;
             m_status = ubdpt_render_passes(m_ctx, first_pass + done_total, chunk, 1, m_seed, &done);
             done_total += done;
             if (m_status != UBDPT_SUCCESS) break;
+            if (m_stop_requested) { m_status = UBDPT_STOPPED; break; }
         }
     } else {
         // With a progress callback the passes are enqueued a few batches at a time (about 16 M pixel-samples per
@@ -121,13 +123,17 @@ bool HipRenderer::renderPassesOnDevice(size_t first_pass, size_t n, size_t* done
             m_status = ubdpt_enqueue_passes(m_ctx, first_pass + done_total, (uint32_t)std::min(per_call, n - done_total), 1, m_seed, &done);
             done_total += done;
             if (m_status != UBDPT_SUCCESS) break;
+            // every enqueue call clears the context's own stop flag on entry (as UBDPTRenderer::renderPass does), so a
+            // request that arrives between two calls, or while a call waits for room on the device, is only seen here
+            if (m_stop_requested) { m_status = UBDPT_STOPPED; break; }
             if (ubdpt_query_progress(m_ctx, nullptr, &fin) == UBDPT_SUCCESS && fin >= enq0) {
                 std::lock_guard<std::mutex> lock(m_progress_mutex);
                 (*progress)(std::min(1.0, (double)(fin - enq0) / total));
             }
         }
+        // what was enqueued is finished in any case: the passes counted in done_total are in the device sum
         const int sync = ubdpt_synchronize(m_ctx);
-        if (m_status == UBDPT_SUCCESS) m_status = sync;
+        if (m_status == UBDPT_SUCCESS || (m_status == UBDPT_STOPPED && sync != UBDPT_SUCCESS)) m_status = sync;
         if (m_status == UBDPT_SUCCESS) {
             std::lock_guard<std::mutex> lock(m_progress_mutex);
             (*progress)(1.0);

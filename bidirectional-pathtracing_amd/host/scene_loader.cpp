@@ -1,6 +1,9 @@
 // scene_loader.cpp — see scene_loader.h.
 #include "scene_loader.h"
 
+#include <new>
+#include <exception>
+
 #include "asset_formats.h"
 
 #include <cmath>
@@ -528,8 +531,14 @@ struct uhip_scene {
 };
 
 uhip_scene* uhip_scene_load_xml(const char* xml_path, const char* base_dir) {
-    auto* h = new uhip_scene();
-    h->scene = uhip::LoadedScene::fromXml(xml_path ? xml_path : "", base_dir ? base_dir : "", h->error);
+    auto* h = new (std::nothrow) uhip_scene();
+    if (!h) return nullptr;
+    try {  // no exception crosses the C boundary: a scene too large for the host's memory is a scene that fails to load
+        h->scene = uhip::LoadedScene::fromXml(xml_path ? xml_path : "", base_dir ? base_dir : "", h->error);
+    } catch (const std::exception& e) {
+        h->scene.reset();
+        h->error = std::string("loading failed: ") + e.what();
+    }
     return h;
 }
 int uhip_scene_ok(const uhip_scene* h) { return h && h->scene ? 1 : 0; }

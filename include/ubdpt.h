@@ -130,7 +130,7 @@ typedef struct ubdpt_options {
                                      (overrides passes_in_flight); small batches keep the path vertices cache-resident */
     uint32_t pass_slots;        /* per-pass sum buffers held on the device besides the sum buffer (0: none, max 64);
                                    ubdpt_render_passes_separate keeps up to that many passes of a call apart */
-    uint32_t traversal_stack_entries; /* entries of a ray's traversal stack; 0 -> 108 (the maximum: 12 on chip, 96 in
+    uint32_t traversal_stack_entries; /* entries of a ray's traversal stack; 0 -> 112 (the maximum: 16 on chip, 96 in
                                    device memory). A ray that needs more makes the call that traced it return UBDPT_ERROR:
                                    a dropped subtree could hide a hit, so such a result is never handed out silently */
 } ubdpt_options;
@@ -303,8 +303,9 @@ int ubdpt_enqueue_passes_separate(ubdpt_context* ctx, uint64_t first_pass, uint3
 /* UScene::intersectionPoint (uengine/uscene.cpp:41-66) for n rays, through the backend's accelerator. */
 int ubdpt_intersect_batch(ubdpt_context* ctx, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits);
 /*
- * No counterpart in the reference. For callers that cannot allocate device memory: code under HIP graph capture,
- * tight serving loops, harnesses that forbid hipMalloc. The same query as ubdpt_intersect_batch, but rays and hits
+ * No counterpart in the reference. For callers that cannot allocate device memory: tight serving loops, harnesses
+ * that forbid hipMalloc, code that runs between the captures of HIP graphs (the call itself waits for its kernel and
+ * reads a counter back, so it cannot be part of a capture). The same query as ubdpt_intersect_batch, but rays and hits
  * are DEVICE buffers of the caller, and what the kernel needs besides them (the off-chip part of the traversal
  * stacks, the overflow counter) lives in a fixed array inside the library (12.6 MB per GPU, held until the process
  * ends) instead of in allocated memory: the call makes no hipMalloc / hipFree and allocates nothing on the host.

@@ -237,3 +237,34 @@ def test_engine_stop_discards_the_pass():
         # the flag is reset by the next call, as UBDPTRenderer::renderPass does (ubdptrenderer.cpp:37)
         n = eng.curr_pass
         assert eng.render_pass() == hostapi.USUCCESS and eng.curr_pass == n + 1
+
+
+@pytest.mark.gpu
+def test_engine_stop_with_progress_callback_ends_the_batched_call():
+    """With a progress callback the passes are handed to the device a few batches per call, and every call clears the
+    context's own stop flag on entry: the renderer's flag must end the loop all the same. The stop comes from the
+    callback itself (after it has been heard three times), so it always falls between two enqueue calls."""
+    sc, params = c2(256, 256)
+    npix = 256 * 256
+    per_call = (16 << 20) // npix
+    n = 40 * per_call
+    with hostapi.Engine(sc) as eng:
+        assert eng.new_rendering(params) == hostapi.USUCCESS
+        seen = []
+
+        def cb(f):
+            seen.append(f)
+            if len(seen) == 3:
+                eng.stop()
+
+        st = eng.render_passes(n, cb)
+        assert st == hostapi.USTOPPED
+        assert per_call <= eng.curr_pass <= 5 * per_call < n      # stopped after a few calls, not after all 40
+        got = eng.sum()
+        done = eng.curr_pass
+        # what was rendered stays, and is exactly the passes the counter names
+        with capi.Context(sc, params) as ctx:
+            ctx.render_passes(0, done, SEED)
+            ref = ctx.read_sum()
+        assert np.allclose(got, ref, rtol=1e-12, atol=1e-13)
+        assert eng.render_pass() == hostapi.USUCCESS and eng.curr_pass == done + 1

@@ -360,6 +360,22 @@ def test_image_file_formats(tmp_path):
     (tmp_path / "cut.xml").write_text(XML.replace("checker.ppm", "cut.png"))
     with pytest.raises(RuntimeError, match="Failed to load texture"):
         hostapi.XmlScene(str(tmp_path / "cut.xml"), str(tmp_path))
+    # headers that promise far more pixels than the file can hold: rejected before anything is sized from them
+    # (a 65535 x 65535 run-length TGA of 18 bytes would ask for 17 GB, a 65536 x 65536 16-bit RGBA PNG for 34 GB)
+    import zlib
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    write("huge.tga", struct.pack("<BBBHHBHHHHBB", 0, 0, 10, 0, 0, 0, 0, 0, 65535, 65535, 32, 0))
+    write("huge2.tga", struct.pack("<BBBHHBHHHHBB", 0, 0, 2, 0, 0, 0, 0, 0, 20000, 20000, 32, 0) + b"\0" * 64)
+    write("huge.png", b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 65536, 65536, 16, 6, 0, 0, 0))
+          + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    write("huge2.png", b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 12000, 12000, 8, 6, 0, 0, 0))
+          + chunk(b"IDAT", zlib.compress(b"\0" * 64)) + chunk(b"IEND", b""))
+    write("huge.bmp", b"BM" + struct.pack("<IHHI", 54, 0, 0, 54) + struct.pack("<IiiHHIIiiII", 40, 60000, 60000, 1, 32, 0, 0, 2835, 2835, 0, 0))
+    for name in ("huge.tga", "huge2.tga", "huge.png", "huge2.png", "huge.bmp"):
+        (tmp_path / "huge.xml").write_text(XML.replace("checker.ppm", name))
+        with pytest.raises(RuntimeError, match="Failed to load texture"):
+            hostapi.XmlScene(str(tmp_path / "huge.xml"), str(tmp_path))
 
 
 def test_mesh_file_formats(tmp_path):
