@@ -16,6 +16,9 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "render.h"
 
 namespace ub {
@@ -155,6 +158,89 @@ __global__ void k_hierarchy(const unsigned long long* keys, int n, int32_t* chil
     int lo = i < j ? i : j, hi = i < j ? j : i;
     child0[i] = (lo == gamma) ? ~gamma : gamma;
     child1[i] = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+}
+
+
+// ---- locally-ordered clustering on the Morton order (Meister and Bittner 2018) ------------------------------------
+// The Karras hierarchy splits the sorted run wherever the codes' highest differing bit says so, whatever the boxes look
+// like. Here the sorted primitives start as one cluster each, and in every round a cluster looks kPlocRadius places to
+// the left and right along the Morton order for the partner whose union with it has the smallest surface area; two
+// clusters that choose each other are merged into a node. Rounds repeat until one cluster is left. Candidates are
+// ordered by (area, distance along the order, parity of the lower position, lower position): a total order on pairs,
+// so the smallest pair in reach always chooses itself (every round merges something), and runs of equal boxes pair up
+// even-odd instead of forming chains in which only the first pair is mutual.
+constexpr int kPlocRadius = 8;      // default reach of the search; UBDPT_PLOC_RADIUS overrides it for measurements
+constexpr int kPlocMaxRadius = 64;
+
+__device__ __forceinline__ float unionArea(const FBox& a, const FBox& b) {
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(kB) void k_ploc_nearest(const FBox* boxes, uint32_t m, uint32_t* nn, int radius) {
+    __shared__ FBox tile[kB + 2 * kPlocMaxRadius];
+    const int base = (int)(blockIdx.x * kB) - radius;
+    for (int t = threadIdx.x; t < kB + 2 * radius; t += kB) {
+        const int g = base + t;
+        if (g >= 0 && g < (int)m) tile[t] = boxes[g];
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const FBox me = tile[threadIdx.x + radius];
+    float best_area = __builtin_inff();
+    uint32_t best_dist = 0xffffffffu, best_par = 2, best_lo = 0xffffffffu, best = i;
+    for (int d = -radius; d <= radius; d++) {
+        if (d == 0) continue;
+        const long long j = (long long)i + d;
+        if (j < 0 || j >= (long long)m) continue;
+        const float area = unionArea(me, tile[(int)threadIdx.x + radius + d]);
+        const uint32_t dist = (uint32_t)(d < 0 ? -d : d), lo = (uint32_t)(d < 0 ? j : i), par = lo & 1u;
+        const bool less = area < best_area ||
+                          (area == best_area && (dist < best_dist || (dist == best_dist && (par < best_par || (par == best_par && lo < best_lo)))));
+        if (less) { best_area = area; best_dist = dist; best_par = par; best_lo = lo; best = (uint32_t)j; }
+    }
+    nn[i] = best;
+}
+// flag word of position i: low half 1 when a cluster stays at i after this round (everything but the upper partner of a
+// merge), high half 1 when i is the lower partner of a merge and so makes a node
+__global__ void k_ploc_flags(const uint32_t* nn, uint32_t m, unsigned long long* flags) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    flags[i] = (mutual && j < i) ? 0ULL : (1ULL | ((mutual && i < j) ? (1ULL << 32) : 0ULL));
+}
+// writes the next round's clusters (compacted, order kept) and the nodes of this round's merges; the node of the
+// merge with rank k among this round's merges gets index id_top - 1 - k, so the last merge of all becomes node 0
+__global__ void k_ploc_merge(const uint32_t* nn, const unsigned long long* flags, const unsigned long long* scan, uint32_t m,
+                             const FBox* boxes, const int32_t* ids, FBox* boxes_out, int32_t* ids_out, uint32_t id_top,
+                             int32_t* child0, int32_t* child1) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i];
+    if (!(f & 1ULL)) return;
+    const uint32_t pos = (uint32_t)(scan[i] & 0xffffffffULL);
+    if (f >> 32) {
+        const uint32_t j = nn[i];
+        const uint32_t node = id_top - 1u - (uint32_t)(scan[i] >> 32);
+        child0[node] = ids[i];
+        child1[node] = ids[j];
+        const FBox a = boxes[i], b = boxes[j];
+        FBox u;
+        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+        boxes_out[pos] = u;
+        ids_out[pos] = (int32_t)node;
+    } else {
+        boxes_out[pos] = boxes[i];
+        ids_out[pos] = ids[i];
+    }
+}
+__global__ void k_ploc_init(uint32_t n, int32_t* ids) {
+    const uint32_t i = blockIdx.x * kB + threadIdx.x;
+    if (i < n) ids[i] = ~(int32_t)i;
 }
 
 // One refit level: node i is produced when both children were finished by an earlier launch.
@@ -373,12 +459,62 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
         hipLaunchKernelGGL(k_single_leaf, dim3(1), dim3(1), 0, s, leaf_boxes, nodes, xnodes);
     } else {
         unsigned gi = (n_internal + kB - 1) / kB;
-        hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(kB), 0, s, keys_sorted, (int)n, child0, child1);
+        // binary hierarchy over the sorted primitives: clustering along the Morton order (default), or the Karras radix
+        // tree (UBDPT_BVH_BUILDER=karras; also what is used should the clustering fail to finish)
+        static const bool use_karras = [] { const char* e = getenv("UBDPT_BVH_BUILDER"); return e && !strcmp(e, "karras"); }();
+        static const int ploc_radius = [] { const char* e = getenv("UBDPT_PLOC_RADIUS"); int r = e ? atoi(e) : kPlocRadius; return r < 1 ? 1 : (r > kPlocMaxRadius ? kPlocMaxRadius : r); }();
+        bool clustered = false;
+        if (!use_karras && n >= 2) {
+            FBox* cbox[2] = {nullptr, nullptr};
+            int32_t* cid[2] = {nullptr, nullptr};
+            uint32_t* nn = nullptr;
+            unsigned long long *flags = nullptr, *scan = nullptr;
+            void* scan_tmp = nullptr;
+            size_t scan_bytes = 0;
+            hipError_t pe = hipSuccess;
+            auto pck = [&](hipError_t e) { if (e != hipSuccess && pe == hipSuccess) pe = e; };
+            for (int k = 0; k < 2; k++) { pck(hipMalloc(&cbox[k], sizeof(FBox) * n)); pck(hipMalloc(&cid[k], sizeof(int32_t) * n)); }
+            pck(hipMalloc(&nn, sizeof(uint32_t) * n));
+            pck(hipMalloc(&flags, sizeof(unsigned long long) * n));
+            pck(hipMalloc(&scan, sizeof(unsigned long long) * n));
+            if (pe == hipSuccess) pck(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, flags, scan, (int)n, s));
+            if (pe == hipSuccess) pck(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
+            if (pe == hipSuccess) {
+                pck(hipMemcpyAsync(cbox[0], leaf_boxes, sizeof(FBox) * n, hipMemcpyDeviceToDevice, s));
+                hipLaunchKernelGGL(k_ploc_init, dim3(g), dim3(kB), 0, s, n, cid[0]);
+                uint32_t m = n, id_top = n_internal;
+                int cur = 0;
+                for (int round = 0; round < 1024 && m > 1 && pe == hipSuccess; round++) {
+                    const unsigned gm = (m + kB - 1) / kB;
+                    hipLaunchKernelGGL(k_ploc_nearest, dim3(gm), dim3(kB), 0, s, cbox[cur], m, nn, ploc_radius);
+                    hipLaunchKernelGGL(k_ploc_flags, dim3(gm), dim3(kB), 0, s, nn, m, flags);
+                    pck(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, flags, scan, (int)m, s));
+                    hipLaunchKernelGGL(k_ploc_merge, dim3(gm), dim3(kB), 0, s, nn, flags, scan, m, cbox[cur], cid[cur],
+                                       cbox[cur ^ 1], cid[cur ^ 1], id_top, child0, child1);
+                    unsigned long long last_scan = 0, last_flag = 0;
+                    pck(hipMemcpyAsync(&last_scan, scan + (m - 1), sizeof(last_scan), hipMemcpyDeviceToHost, s));
+                    pck(hipMemcpyAsync(&last_flag, flags + (m - 1), sizeof(last_flag), hipMemcpyDeviceToHost, s));
+                    pck(hipStreamSynchronize(s));
+                    const unsigned long long tot = last_scan + last_flag;
+                    const uint32_t kept = (uint32_t)(tot & 0xffffffffULL), merged = (uint32_t)(tot >> 32);
+                    if (merged == 0 || kept + merged != m) break;  // cannot happen (the smallest pair in reach is mutual)
+                    m = kept;
+                    id_top -= merged;
+                    cur ^= 1;
+                }
+                clustered = pe == hipSuccess && m == 1 && id_top == 0;
+            }
+            for (int k = 0; k < 2; k++) { hipFree(cbox[k]); hipFree(cid[k]); }
+            hipFree(nn); hipFree(flags); hipFree(scan); hipFree(scan_tmp);
+            if (pe != hipSuccess) { err = pe; goto done; }
+        }
+        if (!clustered)
+            hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(kB), 0, s, keys_sorted, (int)n, child0, child1);
         CK(hipMemsetAsync(ready, 0, sizeof(uint32_t) * n_internal, s));
         CK(hipMemsetAsync(progress, 0, sizeof(uint32_t), s));
         uint32_t done_nodes = 0, level = 1;
         // tree depth is bounded by the key length plus the index tie-break bits
-        while (done_nodes < n_internal && level <= 160) {
+        while (done_nodes < n_internal && level <= 4096) {
             for (int rep = 0; rep < 8; rep++, level++)
                 hipLaunchKernelGGL(k_refit_level, dim3(gi), dim3(kB), 0, s, (int)n_internal, child0, child1, leaf_boxes,
                                    node_boxes, ready, level, bin, progress);
@@ -394,7 +530,7 @@ hipError_t buildLbvh(const DObject* d_objects, const Prim* d_prims_unsorted, uin
             CK(hipMemcpyAsync(depth, &zero, sizeof(uint32_t), hipMemcpyHostToDevice, s));
             CK(hipMemsetAsync(progress, 0, sizeof(uint32_t), s));
             uint32_t seen = 0, before = 0xffffffffu, lv = 0;
-            while (seen != before && lv <= 320) {
+            while (seen != before && lv <= 4096) {
                 before = seen;
                 for (int rep = 0; rep < 8; rep++, lv++)
                     hipLaunchKernelGGL(k_collapse_level, dim3(gi), dim3(kB), 0, s, (int)n_internal, bin, depth, lv, nodes,
