@@ -57,14 +57,14 @@ def host_threads():
     return max(1, min(share, avail) if share > 0 else avail)
 
 
-def algorithmic_bytes(k, node_bytes_scale=1.0):
+def algorithmic_bytes(k, nodes, prims):
     """Algorithmic bytes of one kernel's counted work: closest-hit ray 32 B in + 32 B out, shadow ray
     32 B in + 4 B out, 64 B per tree node, 48 B per primitive tested, 96 B per path vertex written
     (subpath kernels) or read (connection kernel), 24 B per framebuffer read-modify-write.
-    The node / primitive counts are those of the CPU oracle's binary tree (64-byte nodes) on the same workload
-    when it has one (mesh scenes); otherwise the device's own four-wide node visits priced at 64 B each."""
-    return (64.0 * k["closest_hit_rays"] + 36.0 * k["shadow_rays"] + 64.0 * k["nodes"]
-            + 48.0 * k["prims"] + 96.0 * k["vertices"] + 24.0 * k["fb_updates"])
+    nodes / prims: the traversal counts to price (the CPU oracle's binary tree, the device's own tree, or 0 for the
+    compulsory-only figure)."""
+    return (64.0 * k["closest_hit_rays"] + 36.0 * k["shadow_rays"] + 64.0 * nodes
+            + 48.0 * prims + 96.0 * k["vertices"] + 24.0 * k["fb_updates"])
 
 
 def measure_work(scene, params, device, passes, seed, accel, pipeline=0, ref_tree=None):
@@ -79,7 +79,7 @@ def measure_work(scene, params, device, passes, seed, accel, pipeline=0, ref_tre
         ctx.render_passes(0, passes, seed)
         s = ctx.stats()
     ps = float(s["pixel_samples"])
-    per_kernel = {}
+    per_kernel, per_kernel_device, per_kernel_compulsory = {}, {}, {}
     ev = s["eye_vertices"]; lv = s["light_vertices"]
     # vertex records: the generation kernel writes the lens and the emitter vertex of every
     # pixel-sample, the bounce / tail / per-path kernels the rest (split by their share of closest-hit
@@ -108,15 +108,20 @@ def measure_work(scene, params, device, passes, seed, accel, pipeline=0, ref_tre
             kk["vertices"] = rest * writer_rays[k["name"]] / wrays
         else:
             kk["vertices"] = 0
+        dev_nodes, dev_prims = k["nodes_visited"], k["prims_tested"]
         if ref_tree is not None:
-            kk["nodes"] = k["closest_hit_rays"] * ref_tree["nodes_closest"] + k["shadow_rays"] * ref_tree["nodes_shadow"]
-            kk["prims"] = k["closest_hit_rays"] * ref_tree["prims_closest"] + k["shadow_rays"] * ref_tree["prims_shadow"]
+            ref_nodes = k["closest_hit_rays"] * ref_tree["nodes_closest"] + k["shadow_rays"] * ref_tree["nodes_shadow"]
+            ref_prims = k["closest_hit_rays"] * ref_tree["prims_closest"] + k["shadow_rays"] * ref_tree["prims_shadow"]
         else:
-            kk["nodes"], kk["prims"] = k["nodes_visited"], k["prims_tested"]
-        per_kernel[k["name"]] = algorithmic_bytes(kk) / ps
+            ref_nodes, ref_prims = dev_nodes, dev_prims
+        per_kernel[k["name"]] = algorithmic_bytes(kk, ref_nodes, ref_prims) / ps
+        per_kernel_device[k["name"]] = algorithmic_bytes(kk, dev_nodes, dev_prims) / ps
+        per_kernel_compulsory[k["name"]] = algorithmic_bytes(kk, 0.0, 0.0) / ps
     rays = max(1.0, s["closest_hit_rays"] + s["shadow_rays"])
     return {
-        "bytes_per_pixel_sample": per_kernel,
+        "bytes_per_pixel_sample": per_kernel,                        # traversal priced with the CPU oracle's tree (mesh scenes)
+        "bytes_per_pixel_sample_device_counts": per_kernel_device,   # traversal priced with the device tree's own node / primitive visits
+        "bytes_per_pixel_sample_compulsory": per_kernel_compulsory,  # traversal terms dropped
         "rays_per_pixel_sample": (s["closest_hit_rays"] + s["shadow_rays"]) / ps,
         "closest_per_pixel_sample": s["closest_hit_rays"] / ps,
         "shadow_per_pixel_sample": s["shadow_rays"] / ps,
@@ -149,18 +154,22 @@ def cpu_baseline(config, scene, params, seed, budget_s=12.0):
     build_s = time.perf_counter() - t
     npix = int(sp.img_res_x * sp.img_res_y)
     t = time.perf_counter()
-    orc.render_passes(0, 1, seed, num_threads=cores)
+    orc.render_passes(0, 1, seed, num_threads=cores)   # warm-up pass, excluded
     t1 = time.perf_counter() - t
-    n = int(max(1, min(256, budget_s / max(t1, 1e-3))))
-    t = time.perf_counter()
-    img, cn = orc.render_passes(1, n, seed, num_threads=cores, counters=True)
-    dt = time.perf_counter() - t
+    reps = 3
+    n = int(max(1, min(256, budget_s / reps / max(t1, 1e-3))))
+    times = []
+    for r in range(reps):   # three repetitions over different passes of the same workload; the median is reported
+        t = time.perf_counter()
+        img, cn = orc.render_passes(1 + r * n, n, seed, num_threads=cores, counters=True)
+        times.append(time.perf_counter() - t)
+    dt = float(np.median(times))
     rays = cn["closest_hit_rays"] + cn["shadow_rays"]
     out = {
         "value": npix * n / dt / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-        "host_cpus": os.cpu_count(),
-        "sample": (f"{n} passes of the {config} scene at {int(sp.img_res_x)}x{int(sp.img_res_y)} "
-                   f"({npix * n} pixel-samples, {dt:.1f} s), fp64 restatement of the reference, "
+        "host_cpus": os.cpu_count(), "repetitions": reps, "seconds_per_repetition": [round(x, 3) for x in times],
+        "sample": (f"median of {reps} repetitions of {n} passes of the {config} scene at {int(sp.img_res_x)}x{int(sp.img_res_y)} "
+                   f"({npix * n} pixel-samples each, {dt:.1f} s), fp64 restatement of the reference, "
                    + ("per-mesh bounding-volume hierarchy (Mode B; the reference's scan of every face is not runnable at this size)"
                       if mesh else "linear scans in the reference's order")
                    + f", {cores} threads = the CPU share of this job (host has {os.cpu_count()} CPUs)"),
@@ -221,10 +230,12 @@ def timed_run(ctx, args, steps, pps, rank, ngpu, dist, sum_dev, device):
 
     sync_all()
     t0 = time.perf_counter()
+    per_step = pps * ngpu if args.scaling == "weak" else pps   # passes of one step over all GPUs
     for s in range(steps):
-        # step s covers passes [s * pps * ngpu, (s + 1) * pps * ngpu); this rank takes every ngpu-th of them
-        first, count, stride = multigpu.partition_passes(s * pps * ngpu, pps * ngpu, rank, ngpu)
-        ctx.enqueue_passes(first, count, args.seed, pass_stride=stride)
+        # step s covers passes [s * per_step, (s + 1) * per_step); this rank takes every ngpu-th of them
+        first, count, stride = multigpu.partition_passes(s * per_step, per_step, rank, ngpu)
+        if count:
+            ctx.enqueue_passes(first, count, args.seed, pass_stride=stride)
     ctx.read_sum_device(sum_dev.data_ptr())  # waits for the enqueued passes
     multigpu.reduce_sum(sum_dev, dist)
     sync_all()
@@ -274,6 +285,9 @@ def main():
     ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--batch-pixel-samples", type=int, default=0, help="sub-pass batches of this many pixels (0 = whole passes)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every GPU renders steps x passes-per-step passes (default); strong: the N GPUs share them "
+                         "(C4 as BASELINE.json names it: 256 spp in total on 1 / 2 / 4 / 8 GPUs = the default 16 steps x 16 passes)")
     ap.add_argument("--seed", type=lambda x: int(x, 0), default=0x5EED)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
@@ -333,32 +347,72 @@ def main():
     elapsed = timed_run(ctx, args, args.steps, pps, rank, ngpu, dist, sum_dev, device)
 
     if rank == 0:
-        total_passes = args.steps * pps * ngpu
+        total_passes = args.steps * pps * (ngpu if args.scaling == "weak" else 1)
         pixel_samples = total_passes * npix
         value = pixel_samples / elapsed / 1e6
         st = ctx.stats()
         kernels = {k["name"]: k for k in st["kernels"]}
-        dom = max((k for k in kernels.values() if work["bytes_per_pixel_sample"].get(k["name"])), key=lambda k: k["ms"])
-        dom_ms = dom["ms"] / max(1, dom["launches"])
-        # bytes of one launch = bytes per pixel-sample x pixel-samples this GPU rendered / launches of the kernel
-        dom_bytes = work["bytes_per_pixel_sample"].get(dom["name"], 0.0) * (pixel_samples / ngpu) / max(1, dom["launches"])
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # measured HBM bytes per launch: only from a counter profile of THIS configuration (profiles/traffic.json)
-        traffic = None
+        batch_ps, lanes, wf_depth = ctx.batch_info()
+        ps_gpu = pixel_samples / ngpu   # pixel-samples this GPU rendered in the timed region
+        # measured fabric bytes per launch: only from a counter profile of THIS configuration (profiles/traffic.json),
+        # taken with batches of `_batch_pixel_samples` pixel-samples
+        traffic_cfg = {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(args.config, {}).get(dom["name"])
+                traffic_cfg = json.load(open(tf)).get(args.config, {})
             except Exception:
-                traffic = None
+                traffic_cfg = {}
+        tr_batch = float(traffic_cfg.get("_batch_pixel_samples", 0) or 0)
+        batches = kernels["k_wf_gen"]["launches"] if "k_wf_gen" in kernels else 0   # one generation launch per batch
+
+        def kernel_line(k):
+            """Roofline figures of one kernel: algorithmic bytes of a launch / mean HIP-event duration of a launch."""
+            name, launches = k["name"], max(1, k["launches"])
+            ms = k["ms"] / launches
+            out_k = {"kernel": name, "ms_total": k["ms"], "ms_per_launch": ms, "launches": k["launches"]}
+            for key, field in (("frac", "bytes_per_pixel_sample"), ("frac_device_counts", "bytes_per_pixel_sample_device_counts"),
+                               ("frac_compulsory", "bytes_per_pixel_sample_compulsory")):
+                b = work[field].get(name, 0.0) * ps_gpu / launches
+                out_k[key] = (b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
+                if key == "frac":
+                    out_k["algorithmic_bytes_per_launch"] = b
+            t = traffic_cfg.get(name)
+            if t is not None and tr_batch > 0 and batches > 0:
+                per_batch = k["launches"] / batches                      # launches of this kernel per batch
+                scale = batch_ps / tr_batch                              # batch of this run against the profiled one
+                out_k["traffic"] = t * scale                             # counter bytes per launch, at this run's batch size
+                alg = work["bytes_per_pixel_sample"].get(name, 0.0) * tr_batch / per_batch
+                out_k["traffic_over_algorithmic"] = t / alg if alg > 0 else None
+                out_k["frac_traffic"] = (t * scale / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms > 0 else 0.0
+            return out_k
+
+        lines = sorted((kernel_line(k) for k in kernels.values() if work["bytes_per_pixel_sample"].get(k["name"])),
+                       key=lambda x: -x["ms_total"])
+        dom = lines[0]
+        dom_ms, dom_bytes = dom["ms_per_launch"], dom["algorithmic_bytes_per_launch"]
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = dom.get("traffic")
+        # whole pipeline: bytes of every kernel per pixel-sample x pixel-samples per second
+        pps_rate = ps_gpu / elapsed
+        pipeline = {
+            "algorithmic_gbs": sum(work["bytes_per_pixel_sample"].values()) * pps_rate / 1e9,
+            "device_counts_gbs": sum(work["bytes_per_pixel_sample_device_counts"].values()) * pps_rate / 1e9,
+            "compulsory_gbs": sum(work["bytes_per_pixel_sample_compulsory"].values()) * pps_rate / 1e9,
+        }
+        if tr_batch > 0 and batches > 0:
+            tot = sum(traffic_cfg[n] * (k["launches"] / batches) for n, k in kernels.items() if n in traffic_cfg)
+            pipeline["hbm_gbs"] = tot / tr_batch * pps_rate / 1e9          # sum of counter bytes per pixel-sample x rate
+            pipeline["hbm_frac_of_peak"] = pipeline["hbm_gbs"] / HBM_PEAK_GBS
+            pipeline["counter_bytes_per_pixel_sample"] = tot / tr_batch
         img = sum_dev.cpu().numpy()
         out = {
             "metric": "bdpt_mpaths_per_s", "value": value, "unit": "Mpaths/s", "n_gpus": ngpu, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {WORKLOADS.get(args.config, 'synthetic scene')}, {W}x{H}",
                        "triangles": int(scene.num_faces), "passes_per_step": pps, "spp_total": total_passes,
-                       "passes_per_gpu": args.steps * pps,
+                       "passes_per_gpu": total_passes / ngpu,
                        "accel": "lbvh" if args.accel == 0 else "linear", "pipeline": args.pipeline,
                        "passes_in_flight": args.passes_in_flight or "auto", "max_path_vertices": args.max_path_vertices or 32, "streams": args.streams or "default",
                        "wavefront_depth": args.wavefront_depth or "default", "partition": f"passes round-robin over {ngpu} GPU(s)"},
@@ -374,10 +428,18 @@ def main():
             "kernels": {k: {"ms_per_launch": v["ms"] / max(1, v["launches"]), "launches": v["launches"],
                             "algorithmic_bytes_per_pixel_sample": work["bytes_per_pixel_sample"].get(k)}
                         for k, v in kernels.items()},
-            "roofline": {"bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": dom_bytes, "ms_per_launch": dom_ms,
-                         "node_counts_from": "cpu oracle tree (64-byte binary nodes)" if ref_tree else "device (four-wide node visits priced at 64 B)"},
+                         "node_counts_from": "cpu oracle tree (64-byte binary nodes)" if ref_tree else "device (four-wide node visits priced at 64 B)",
+                         # the same kernel with the traversal priced by the device tree's own visits, and without traversal
+                         "frac_device_counts": dom["frac_device_counts"], "frac_compulsory": dom["frac_compulsory"],
+                         "frac_traffic": dom.get("frac_traffic"),
+                         # the kernels by total HIP-event time (under two batch lanes a launch's duration includes waiting
+                         # for room beside the other lane's kernels, so the order of close candidates differs between runs)
+                         "candidates": lines[:4],
+                         "pipeline": pipeline},
+            "batch": {"pixel_samples": batch_ps, "lanes": lanes, "wavefront_depth": wf_depth},
         }
         if cb is not None:
             out["cpu_baseline"] = cb

@@ -110,7 +110,7 @@ EXPORTS = [
     "ubdpt_read_sum_slot_onto",
     "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
-    "ubdpt_get_image_size", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
+    "ubdpt_get_image_size", "ubdpt_get_batch_info", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch", "ubdpt_connection_probe",
 ]
 
@@ -182,6 +182,7 @@ def load_library(path=None):
     lib.ubdpt_get_object_info.argtypes = [vp, C.c_uint32, vp, vp, vp, vp]
     lib.ubdpt_get_camera_info.argtypes = [vp, vp, vp, vp]
     lib.ubdpt_get_image_size.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.ubdpt_get_batch_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.ubdpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.ubdpt_reset_stats.argtypes = [vp]
     lib.ubdpt_connection_probe.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
@@ -193,6 +194,13 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def device_count():
+    """GPUs the HIP runtime of the backend sees (0 when there is none)."""
+    n = C.c_int(0)
+    load_library().ubdpt_device_count(C.byref(n))
+    return n.value
 
 
 class UbdptError(RuntimeError):
@@ -348,6 +356,12 @@ class Context:
         _check(self.lib.ubdpt_get_camera_info(self.handle, v.ctypes.data, iv.ctypes.data, C.addressof(d)),
                "ubdpt_get_camera_info")
         return v, iv, d.value
+
+    def batch_info(self):
+        """(pixel-samples per batch, lanes, wavefront depth) the context settled on."""
+        n, l, d = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
+        _check(self.lib.ubdpt_get_batch_info(self.handle, C.byref(n), C.byref(l), C.byref(d)), "ubdpt_get_batch_info")
+        return n.value, l.value, d.value
 
     def stats(self):
         s = Stats()

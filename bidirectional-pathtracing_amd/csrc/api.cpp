@@ -294,10 +294,12 @@ constexpr uint64_t kMaxGridLanes = 2048ull * 256;  // lanes of the largest grid 
 #define HIPCK(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->last_hip = e_; \
     fprintf(stderr, "ubdpt: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return UBDPT_HIP_ERROR; } } while (0)
 
+// (silent: the caller retries with smaller batches when the memory does not suffice, and reports the failure that remains)
 int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv) {
     P.n = n; P.maxv = maxv; P.count_stride = 1;
-    HIPCK(c, hipMalloc((void**)&P.v, sizeof(double) * kVertexDoubles * maxv * n));
-    HIPCK(c, hipMalloc((void**)&P.count, sizeof(uint32_t) * n));
+    hipError_t e = hipMalloc((void**)&P.v, sizeof(double) * kVertexDoubles * maxv * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&P.count, sizeof(uint32_t) * n);
+    if (e != hipSuccess) { c->last_hip = e; return UBDPT_HIP_ERROR; }
     return UBDPT_SUCCESS;
 }
 
@@ -566,6 +568,9 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         // so on: smaller batches, same results. UBDPT_MEM_FRACTION overrides the share.
         size_t mem_free = 0, mem_total = 0;
         if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 48ull << 30;
+        // UBDPT_ASSUME_FREE_BYTES: what to take for the free memory instead (tests of the path below that shrinks the
+        // batches when the snapshot was too optimistic, as it is when two contexts are created at the same moment)
+        if (const char* e = getenv("UBDPT_ASSUME_FREE_BYTES")) { const double v = atof(e); if (v >= 1.0) mem_free = (size_t)v; }
         static const double mem_fraction = [] { const char* e = getenv("UBDPT_MEM_FRACTION"); double f = e ? atof(e) : 0.8; return f > 0.05 && f <= 0.95 ? f : 0.8; }();
         const uint64_t lane_budget = std::max<uint64_t>(1ull << 30, (uint64_t)((double)mem_free * mem_fraction) / nstreams);
         while (pif > 1 && laneBytes(pif) > lane_budget) pif--;
@@ -631,16 +636,26 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             if (st != UBDPT_SUCCESS) break;
         }
         if (st == UBDPT_SUCCESS) break;
-        const bool can_shrink = c->cap_paths >= c->npix && (c->passes_in_flight > 1 || nstreams > 1);
-        if (c->last_hip != hipErrorOutOfMemory || !can_shrink || attempt >= 8) break;
+        // out of memory: batches of half the passes, then one lane, then batches of a part of a pass (down to 64 K
+        // pixel-samples); the results do not depend on the batch size
+        const bool can_shrink = c->passes_in_flight > 1 || nstreams > 1 || c->cap_paths > (1ull << 16);
+        if (c->last_hip != hipErrorOutOfMemory || !can_shrink || attempt >= 24) {
+            fprintf(stderr, "ubdpt: HIP error %s while allocating the batch buffers (%llu pixel-samples per batch, %u lane(s))\n",
+                    hipGetErrorString(c->last_hip), (unsigned long long)c->cap_paths, nstreams);
+            break;
+        }
         c->freeLanes();
         (void)hipGetLastError();
         st = UBDPT_SUCCESS;
-        if (c->passes_in_flight > 1) {
+        if (c->passes_in_flight > 1 && c->cap_paths >= c->npix) {
             c->passes_in_flight = (c->passes_in_flight + 1) / 2;
             c->cap_paths = c->npix * c->passes_in_flight;
-        } else
+        } else if (nstreams > 1) {
             nstreams = 1;
+        } else {
+            c->passes_in_flight = 1;
+            c->cap_paths = std::max<uint64_t>(1ull << 16, ((c->cap_paths / 2) + 255) / 256 * 256);
+        }
         }
         if (st != UBDPT_SUCCESS) break;
         // set-up of the entry point that allocates nothing: this GPU's address of the static scratch array (asked for with
@@ -1270,6 +1285,14 @@ int ubdpt_get_image_size(ubdpt_context* c, uint64_t* width, uint64_t* height) {
     if (!c) return UBDPT_INVALID_ARG;
     if (width) *width = c->params.img_res_x;
     if (height) *height = c->params.img_res_y;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_get_batch_info(ubdpt_context* c, uint64_t* pixel_samples_per_batch, uint32_t* lanes, uint32_t* wavefront_depth) {
+    if (!c) return UBDPT_INVALID_ARG;
+    if (pixel_samples_per_batch) *pixel_samples_per_batch = c->cap_paths;
+    if (lanes) *lanes = (uint32_t)c->lanes.size();
+    if (wavefront_depth) *wavefront_depth = c->wf_depth;
     return UBDPT_SUCCESS;
 }
 

@@ -3,6 +3,7 @@
 #include "hip_renderer.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -24,31 +25,13 @@ bool HipRenderer::initialize(const RenderParameters& render_params, std::shared_
     ubdpt_scene_desc desc;
     std::memset(&desc, 0, sizeof(desc));
     if (!scene->flatten(desc)) { m_status = UBDPT_INVALID_SCENE; return false; }
-    // window of passes rendered at once for renderPass: about 16 M pixel-samples, at most 32 passes (measured pass by
-    // pass: 2 / 4 / 8 passes per window at 1080p on a 2 M-triangle scene 243 / 259 / 282 Mpaths/s, 16 / 32 passes at
-    // 512 x 512 359 / 402); two windows of per-pass buffers, so that the device renders one while the host consumes the other
+    // per-pass device buffers for renderPass: two windows of passes rendered ahead (pass_windows.h)
     ubdpt_options opt = m_options;
-    if (opt.pass_slots == 0) {
-        const uint64_t npix = (uint64_t)render_params.img_res_x * render_params.img_res_y;
-        opt.pass_slots = 2 * (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(32, npix ? (1ull << 24) / npix : 1));
-    }
+    if (opt.pass_slots == 0) opt.pass_slots = PassWindows::slotsFor(render_params.img_res_x, render_params.img_res_y);
     opt.pass_slots = std::min<uint32_t>(opt.pass_slots, 64);
-    m_two_windows = opt.pass_slots >= 2;
-    m_window_slots = m_two_windows ? opt.pass_slots / 2 : 1;
-    m_window = Window{};
-    m_next_window = Window{};
     m_status = ubdpt_create(&desc, &render_params, &opt, m_device, &m_ctx);
+    m_windows.reset(opt.pass_slots);
     return m_status == UBDPT_SUCCESS;
-}
-
-// passes first_pass .. first_pass + window - 1, each into its own device sum buffer of the given half; not waited for
-bool HipRenderer::enqueueWindow(Window& w, size_t first_pass, uint32_t half) {
-    w = Window{};
-    uint32_t done = 0;
-    m_status = ubdpt_enqueue_passes_separate(m_ctx, first_pass, m_window_slots, 1, m_seed, half * m_window_slots, &done);
-    if (m_status != UBDPT_SUCCESS || done == 0) return false;   // stopped: the engine drops the write buffer
-    w.first = first_pass; w.count = done; w.seed = m_seed; w.half = half;
-    return true;
 }
 
 bool HipRenderer::renderPass(std::shared_ptr<SumBuffer> pixel_buffer, size_t curr_pass, size_t num_threads,
@@ -60,25 +43,12 @@ bool HipRenderer::renderPassOnto(const SumBuffer* prev, std::shared_ptr<SumBuffe
                                  size_t num_threads, std::function<void(double)>& update_progress_callback) {
     if (!m_ctx || !pixel_buffer || !prev) { m_status = UBDPT_UNINITIALIZED; return false; }
     m_stop_requested = false;  // UBDPTRenderer::renderPass resets m_stop on entry (ubdptrenderer.cpp:37)
-    if (!m_window.holds(curr_pass, m_seed)) {
-        if (m_next_window.holds(curr_pass, m_seed)) {
-            m_window = m_next_window;
-            m_next_window = Window{};
-        } else {
-            m_next_window = Window{};
-            if (!enqueueWindow(m_window, curr_pass, 0)) return false;
-        }
-        // the passes after this window go to the other half of the buffers right away
-        if (m_two_windows && m_window.count == m_window_slots)
-            enqueueWindow(m_next_window, m_window.first + m_window.count, m_window.half ^ 1u);
-    }
-    // this pass is added to the caller's running sum (waits for the window the pass belongs to, not for the next one)
-    m_status = ubdpt_read_sum_slot_onto(m_ctx, m_window.half * m_window_slots + (uint32_t)(curr_pass - m_window.first),
-                                        prev->ptr(), pixel_buffer->ptr(), (uint32_t)std::min<size_t>(std::max<size_t>(num_threads, 1), 16));
+    // this pass is added to the caller's running sum
+    m_status = m_windows.servePass(m_ctx, curr_pass, m_seed, prev->ptr(), pixel_buffer->ptr(), (uint32_t)std::min<size_t>(num_threads, 64));
     if (m_status != UBDPT_SUCCESS) return false;
     if (m_stop_requested) {  // stop() arrived during this call
         m_status = UBDPT_STOPPED;
-        m_window = Window{}; m_next_window = Window{};
+        m_windows.drop();
         return false;
     }
     if (update_progress_callback != nullptr) {
@@ -357,6 +327,36 @@ int uhip_ur_read(const char* filename, uint64_t* curr_pass, ubdpt_render_params*
         std::memcpy(sums, v.data(), sizeof(double) * v.size());
     }
     return r;
+}
+
+// Times the loop the reference's engine runs around the URenderer subclass of host/reference_adapter/
+// (uengine/uengine.cpp:144-180: copy the read buffer into the write buffer, renderPass adds one pass to it, swap), with
+// the calls that subclass makes: PassWindows::slotsFor at create, PassWindows::servePass(sum, sum) per pass. `warmup`
+// passes first, then `passes` timed ones; engine_copy = 0 leaves out the engine's own copy (what the renderer alone
+// costs). Returns the seconds of the timed passes, negative on failure.
+double uhip_adapter_pass_rate(const ubdpt_scene_desc* desc, const ubdpt_render_params* params, int device, size_t warmup,
+                              size_t passes, size_t num_threads, int engine_copy) {
+    if (!desc || !params) return -1.0;
+    ubdpt_options opt{};
+    opt.pass_slots = uhip::PassWindows::slotsFor(params->img_res_x, params->img_res_y);
+    ubdpt_context* ctx = nullptr;
+    if (ubdpt_create(desc, params, &opt, device, &ctx) != UBDPT_SUCCESS) return -1.0;
+    uhip::PassWindows windows;
+    windows.reset(opt.pass_slots);
+    uhip::SumBuffer a(params->img_res_x, params->img_res_y), b(params->img_res_x, params->img_res_y);
+    uhip::SumBuffer* rd = &a;
+    uhip::SumBuffer* wr = &b;
+    double seconds = -1.0;
+    std::chrono::steady_clock::time_point t0;
+    for (size_t pass = 0; pass < warmup + passes; pass++) {
+        if (pass == warmup) t0 = std::chrono::steady_clock::now();
+        if (engine_copy && pass != 0) wr->setFrom(*rd);                                  // uengine.cpp:153-156
+        if (windows.servePass(ctx, pass, 0x5EED, wr->ptr(), wr->ptr(), (uint32_t)num_threads) != UBDPT_SUCCESS) { seconds = -2.0; break; }
+        std::swap(rd, wr);                                                               // :167-174
+        if (pass + 1 == warmup + passes) seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    ubdpt_destroy(ctx);
+    return seconds;
 }
 
 }  // extern "C"

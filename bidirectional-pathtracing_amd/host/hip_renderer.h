@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/ubdpt.h"
+#include "pass_windows.h"
 
 namespace uhip {
 
@@ -109,25 +110,7 @@ private:
     uint64_t m_seed = 0x5EED;
     int m_status = UBDPT_SUCCESS;
     std::mutex m_progress_mutex;  // the reference serialises its progress callback (ubdptrenderer.cpp:54-62)
-    // renderPass hands back one pass per call, but one pass is a small batch for the device (a fraction of a
-    // millisecond of work behind two dozen launches). The adapter therefore renders a window of consecutive passes
-    // at once into separate device sum buffers (ubdpt_render_passes_separate) and serves the following calls from
-    // it; a call outside the window (or after initialize or a change of seed) starts a new one. The device sum the
-    // batched entry points work on is a different buffer and is not disturbed. The device holds two such windows:
-    // as soon as one becomes the current window, the next one (the passes right after it, which is what the
-    // engine asks for next) is enqueued into the other half of the buffers (ubdpt_enqueue_passes_separate), so the
-    // device renders it while the host consumes the current one. A stop or a jump to another pass wastes at most
-    // that one window of device work.
-    struct Window {
-        size_t first = 0, count = 0;
-        uint64_t seed = 0;
-        uint32_t half = 0;
-        bool holds(size_t pass, uint64_t s) const { return count != 0 && seed == s && pass >= first && pass < first + count; }
-    };
-    bool enqueueWindow(Window& w, size_t first_pass, uint32_t half);
-    uint32_t m_window_slots = 1;    // passes per window
-    bool m_two_windows = false;     // the context holds 2 * m_window_slots per-pass buffers
-    Window m_window, m_next_window;
+    PassWindows m_windows;        // renderPass is served from windows of passes rendered ahead (pass_windows.h)
     std::atomic<bool> m_stop_requested{false};
 };
 

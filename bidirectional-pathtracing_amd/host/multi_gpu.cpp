@@ -107,8 +107,8 @@ bool MultiGpuRenderer::renderPasses(size_t first_pass, size_t n, uint64_t seed, 
     return ok;
 }
 
-bool MultiGpuRenderer::reduceSum(SumBuffer& out) {
-    if (m_ctx.empty() || out.width() != m_width || out.height() != m_height) { m_status = UBDPT_INVALID_ARG; return false; }
+const double* MultiGpuRenderer::reduceSumOnDevice() {
+    if (m_ctx.empty()) { m_status = UBDPT_UNINITIALIZED; return nullptr; }
     const size_t count = 3 * m_width * m_height;
     // per device: the first context's sum replaces the partial buffer, the others are added to it
     for (size_t r = 0; r < m_unique.size(); r++) {
@@ -117,30 +117,43 @@ bool MultiGpuRenderer::reduceSum(SumBuffer& out) {
             if (m_devices[k] != m_unique[r]) continue;
             int s = first ? ubdpt_read_sum_device(m_ctx[k], m_partial[r]) : ubdpt_accumulate_sum_device(m_ctx[k], m_partial[r]);
             first = false;
-            if (s != UBDPT_SUCCESS) { m_status = s; return false; }
+            if (s != UBDPT_SUCCESS) { m_status = s; return nullptr; }
         }
     }
     // one reduce(sum) to the first device; a single process drives all ranks, so the calls form one group
-    if (!ncclOk(ncclGroupStart(), "ncclGroupStart")) { m_status = UBDPT_HIP_ERROR; return false; }
+    if (!ncclOk(ncclGroupStart(), "ncclGroupStart")) { m_status = UBDPT_HIP_ERROR; return nullptr; }
     for (size_t r = 0; r < m_unique.size(); r++) {
         if (!hipOk(hipSetDevice(m_unique[r]), "hipSetDevice") ||
             !ncclOk(ncclReduce(m_partial[r], m_partial[r], count, ncclDouble, ncclSum, 0, static_cast<ncclComm_t>(m_comms[r]), nullptr),
                     "ncclReduce")) {
             ncclGroupEnd();
             m_status = UBDPT_HIP_ERROR;
-            return false;
+            return nullptr;
         }
     }
-    if (!ncclOk(ncclGroupEnd(), "ncclGroupEnd")) { m_status = UBDPT_HIP_ERROR; return false; }
+    if (!ncclOk(ncclGroupEnd(), "ncclGroupEnd")) { m_status = UBDPT_HIP_ERROR; return nullptr; }
     for (size_t r = 0; r < m_unique.size(); r++)
         if (!hipOk(hipSetDevice(m_unique[r]), "hipSetDevice") || !hipOk(hipStreamSynchronize(nullptr), "hipStreamSynchronize")) {
-            m_status = UBDPT_HIP_ERROR; return false;
+            m_status = UBDPT_HIP_ERROR; return nullptr;
         }
-    if (!hipOk(hipSetDevice(m_unique[0]), "hipSetDevice") ||
-        !hipOk(hipMemcpy(out.ptr(), m_partial[0], sizeof(double) * count, hipMemcpyDeviceToHost), "hipMemcpy")) {
+    if (!hipOk(hipSetDevice(m_unique[0]), "hipSetDevice")) { m_status = UBDPT_HIP_ERROR; return nullptr; }
+    return m_partial[0];
+}
+
+bool MultiGpuRenderer::reduceSumTo(double* host_rgb) {
+    if (!host_rgb) { m_status = UBDPT_INVALID_ARG; return false; }
+    const double* total = reduceSumOnDevice();
+    if (!total) return false;
+    // the only copy of the image: device 0 -> the caller's buffer
+    if (!hipOk(hipMemcpy(host_rgb, total, sizeof(double) * 3 * m_width * m_height, hipMemcpyDeviceToHost), "hipMemcpy")) {
         m_status = UBDPT_HIP_ERROR; return false;
     }
     return true;
+}
+
+bool MultiGpuRenderer::reduceSum(SumBuffer& out) {
+    if (out.width() != m_width || out.height() != m_height) { m_status = UBDPT_INVALID_ARG; return false; }
+    return reduceSumTo(out.ptr());
 }
 
 void MultiGpuRenderer::clear() {
@@ -176,10 +189,7 @@ int uhip_multi_render_passes(uhip_multi* m, size_t first_pass, size_t n, uint64_
 }
 int uhip_multi_reduce_sum(uhip_multi* m, double* rgb) {
     if (!m || !rgb) return UBDPT_INVALID_ARG;
-    uhip::SumBuffer b(m->w, m->h);
-    if (!m->r.reduceSum(b)) return m->r.lastStatus();
-    std::memcpy(rgb, b.ptr(), sizeof(double) * 3 * m->w * m->h);
-    return UBDPT_SUCCESS;
+    return m->r.reduceSumTo(rgb) ? UBDPT_SUCCESS : m->r.lastStatus();
 }
 void uhip_multi_clear(uhip_multi* m) { if (m) m->r.clear(); }
 int uhip_reduce_sum_rccl(ubdpt_context* ctx, void* nccl_comm, int root, double* device_buffer, void* hip_stream) {

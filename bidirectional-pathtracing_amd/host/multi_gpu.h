@@ -41,6 +41,11 @@ public:
     // Sum of all contexts' device sums -> out ([y][x][rgb]); through RCCL when more than one device is involved,
     // and through the same ncclReduce call (a communicator of one rank) when not.
     bool reduceSum(SumBuffer& out);
+    bool reduceSumTo(double* host_rgb);   // the same into W * H * 3 doubles of the caller: one copy, device 0 -> host
+    // The reduced sum left on the first device of the list ([y][x][rgb], W * H * 3 doubles, valid until the next
+    // reduce): for a preview every few passes nothing has to cross PCIe but what the caller then makes of it.
+    // nullptr on failure. The first device is current on return.
+    const double* reduceSumOnDevice();
     void clear();  // zeroes every context's device sum
     void stop();
     size_t contexts() const { return m_ctx.size(); }

@@ -1,7 +1,8 @@
 // ubdpthiprenderer.h — file a reference maintainer adds to uengine/: the URenderer (uengine/urenderer.h:10-16)
 // that forwards to the MI355X backend through the C ABI (include/ubdpt.h). Compiles against the reference's own
 // headers; the build of this repository only syntax-checks it (tests/test_adapter_compiles.py), it is not part of
-// any library here. uhip::HipRenderer (../hip_renderer.cpp) is the same logic against GLM-free mirror types.
+// any library here. The serving of passes from windows rendered ahead is uhip::PassWindows (../pass_windows.h), the
+// same object uhip::HipRenderer (../hip_renderer.cpp, the GLM-free mirror this repository tests and times) delegates to.
 #ifndef UBDPTHIPRENDERER_H
 #define UBDPTHIPRENDERER_H
 
@@ -10,6 +11,8 @@
 #include "uflatsceneexport.h"
 
 #include <ubdpt.h>
+#include <pass_windows.h>   // bidirectional-pathtracing_amd/host/pass_windows.h: needs <ubdpt.h> only
+#include <atomic>
 #include <mutex>
 
 class UBDPTHipRenderer : public URenderer
@@ -25,8 +28,12 @@ public:
         if(!exporter->flatten(desc)) return false;
         static_assert(sizeof(URenderParameters) == sizeof(ubdpt_render_params), "uutils.h:11-20");
         if(m_ctx) { ubdpt_destroy(m_ctx); m_ctx = nullptr; }
-        ubdpt_options opt{}; opt.pass_slots = 2 * kSlots; m_win_n = m_next_n = 0;
-        return ubdpt_create(&desc, reinterpret_cast<const ubdpt_render_params*>(&params), &opt, /*device*/0, &m_ctx) == UBDPT_SUCCESS;
+        // per-pass device buffers: two windows of passes rendered ahead, sized by the resolution (pass_windows.h)
+        ubdpt_options opt{};
+        opt.pass_slots = uhip::PassWindows::slotsFor(params.img_res_x, params.img_res_y);
+        const int st = ubdpt_create(&desc, reinterpret_cast<const ubdpt_render_params*>(&params), &opt, /*device*/0, &m_ctx);
+        m_windows.reset(opt.pass_slots);
+        return st == UBDPT_SUCCESS;
     }
 
     // The buffer already holds the sum of all previous passes (uengine.cpp:153-156); add exactly one
@@ -34,39 +41,23 @@ public:
     bool renderPass(std::shared_ptr<UBuffer2D<glm::dvec3>> pixel_buffer, size_t curr_pass, size_t num_threads,
                     std::function<void(double)>& update_progress_callback) override
     {
-        // One pass is a small batch for the device, so a window of kSlots consecutive passes is rendered at once
-        // into per-pass device buffers and served call by call; the device holds two windows (pass_slots =
-        // 2 * kSlots at create) and renders the next one while the host consumes the current one.
-        if(!(m_win_n && curr_pass >= m_win_first && curr_pass < m_win_first + m_win_n))
-        {
-            uint32_t done = 0;
-            if(m_next_n && curr_pass >= m_next_first && curr_pass < m_next_first + m_next_n)
-            {   m_win_first = m_next_first; m_win_n = m_next_n; m_half ^= 1u; }           // already enqueued
-            else
-            {
-                m_win_n = 0; m_half = 0;
-                if(ubdpt_enqueue_passes_separate(m_ctx, curr_pass, kSlots, 1, m_seed, 0, &done) != UBDPT_SUCCESS || done == 0)
-                    return false;                                                      // stopped: UEngine drops the buffer (:176-179)
-                m_win_first = curr_pass; m_win_n = done;
-            }
-            m_next_n = 0;
-            if(m_win_n == kSlots && ubdpt_enqueue_passes_separate(m_ctx, m_win_first + kSlots, kSlots, 1, m_seed, (m_half ^ 1u) * kSlots, &done) == UBDPT_SUCCESS)
-            {   m_next_first = m_win_first + kSlots; m_next_n = done; }
-        }
-        // UBuffer2D<glm::dvec3> is contiguous [y][x] of 3 doubles (uutils.h:37-98)
-        double* sum = reinterpret_cast<double*>(pixel_buffer->ptr());  // += of the pass on the threads this call was given
-        if(ubdpt_read_sum_slot_onto(m_ctx, m_half * kSlots + uint32_t(curr_pass - m_win_first), sum, sum, uint32_t(num_threads)) != UBDPT_SUCCESS) return false;
+        if(m_ctx == nullptr || pixel_buffer == nullptr) return false;
+        m_stop = false;                                                                 // as ubdptrenderer.cpp:37
+        // UBuffer2D<glm::dvec3> is contiguous [y][x] of 3 doubles (uutils.h:37-98): sum += the pass
+        double* sum = reinterpret_cast<double*>(pixel_buffer->ptr());
+        if(m_windows.servePass(m_ctx, curr_pass, m_seed, sum, sum, uint32_t(num_threads)) != UBDPT_SUCCESS)
+            return false;                                                               // stopped: UEngine drops the buffer (:176-179)
+        if(m_stop) { m_windows.drop(); return false; }                                  // stop() arrived during this call
         if(update_progress_callback != nullptr) { std::lock_guard<std::mutex> l(m_progress); update_progress_callback(1.0); }
         return true;
     }
 
-    void stop() override { if(m_ctx) ubdpt_request_stop(m_ctx); }                      // any thread (appmanager.cpp:489-498)
+    void stop() override { m_stop = true; if(m_ctx) ubdpt_request_stop(m_ctx); }        // any thread (appmanager.cpp:489-498)
 
 private:
     ubdpt_context* m_ctx = nullptr;
-    static constexpr uint32_t kSlots = 16;        // about 4 M pixel-samples per window at 512 x 512
-    size_t m_win_first = 0, m_win_n = 0, m_next_first = 0, m_next_n = 0;   // reset in initialize()
-    uint32_t m_half = 0;                           // which half of the per-pass buffers the current window is in
+    uhip::PassWindows m_windows;
+    std::atomic<bool> m_stop{false};
     uint64_t m_seed = 0x5EED;   // the reference seeds from std::random_device (umath.cpp:10-20); any value works
     std::mutex m_progress;
 };

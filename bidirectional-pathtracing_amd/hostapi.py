@@ -19,7 +19,7 @@ EXPORTS = ["uhip_engine_create", "uhip_engine_destroy", "uhip_engine_set_scene",
            "uhip_engine_sum", "uhip_engine_image_rgb", "uhip_engine_save", "uhip_engine_load", "uhip_ur_write",
            "uhip_ur_read", "uhip_scene_load_xml", "uhip_scene_ok", "uhip_scene_error", "uhip_scene_desc",
            "uhip_scene_free", "uhip_multi_create", "uhip_multi_destroy", "uhip_multi_render_passes",
-           "uhip_multi_reduce_sum", "uhip_multi_clear", "uhip_reduce_sum_rccl"]
+           "uhip_multi_reduce_sum", "uhip_multi_clear", "uhip_reduce_sum_rccl", "uhip_adapter_pass_rate"]
 
 _lib = None
 
@@ -64,6 +64,9 @@ def load_library():
         lib.uhip_multi_create.restype = vp
         lib.uhip_multi_create.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.RenderParams), C.POINTER(capi.Options),
                                           C.POINTER(C.c_int), C.c_size_t]
+        lib.uhip_adapter_pass_rate.restype = C.c_double
+        lib.uhip_adapter_pass_rate.argtypes = [C.POINTER(capi.SceneDesc), C.POINTER(capi.RenderParams), C.c_int, C.c_size_t,
+                                               C.c_size_t, C.c_size_t, C.c_int]
         lib.uhip_multi_destroy.restype = None
         lib.uhip_multi_destroy.argtypes = [vp]
         lib.uhip_multi_render_passes.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_size_t)]

@@ -331,6 +331,11 @@ int ubdpt_get_camera_info(ubdpt_context* ctx, double view[16], double inv_view[1
 
 /* img_res_x / img_res_y the context was created with (URenderParameters, uengine/uutils.h:11-20): the size of the sum buffer. */
 int ubdpt_get_image_size(ubdpt_context* ctx, uint64_t* width, uint64_t* height);
+/* How the context batches its work (no counterpart in the reference, whose unit of work is one pixel,
+ * uengine/ubdptrenderer.cpp:43-75): pixel-samples of one batch, batches in flight side by side (lanes), bounces that
+ * run as wavefront launches before the tail loop. What ubdpt_create settled on after sizing the batches to the memory
+ * that was free; the measurement tools relate per-launch counters to pixel-samples with it. Any pointer may be NULL. */
+int ubdpt_get_batch_info(ubdpt_context* ctx, uint64_t* pixel_samples_per_batch, uint32_t* lanes, uint32_t* wavefront_depth);
 
 int ubdpt_get_stats(ubdpt_context* ctx, ubdpt_stats* out);
 int ubdpt_reset_stats(ubdpt_context* ctx);

@@ -19,6 +19,7 @@ def test_adapter_compiles_against_the_reference_interface():
     cmd = ["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-Wextra",
            "-I", os.path.join(ROOT, "tests", "glm_decl_stub"), "-I", REF, "-I", os.path.join(ROOT, "include"),
            "-I", os.path.join(ROOT, "bidirectional-pathtracing_amd", "host", "reference_adapter"),
+           "-I", os.path.join(ROOT, "bidirectional-pathtracing_amd", "host"),
            os.path.join(ROOT, "tests", "adapter_check.cpp")]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout

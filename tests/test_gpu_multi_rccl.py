@@ -68,3 +68,31 @@ def test_partitioned_render_matches_the_oracle_path_by_path():
     bad = float(np.any(err > 1e-9, axis=2).mean())
     print(f"two contexts + RCCL reduce vs oracle: {bad * 100:.3f} % of pixels off by > 1e-9")
     assert bad <= 0.005, bad
+
+
+def test_one_context_per_device_over_every_gpu_of_the_node():
+    """uhip::MultiGpuRenderer over every GPU the process sees (up to 8): ncclCommInitAll over several devices and the
+    grouped ncclReduce across them, which a one-GPU box never executes. Skipped below two devices. The reduced
+    sum must equal the single-context render to rounding of the additions."""
+    n = capi.device_count()
+    if n < 2:
+        pytest.skip("needs at least two GPUs (the communicator of one rank is covered by the tests above)")
+    hostapi = _hostapi()
+    devices = list(range(min(n, 8)))
+    scene = scenes.cornell_c2()
+    params = scenes.make_params(96, 96)
+    passes = 3 * len(devices) + 1
+    with hostapi.MultiGpu(scene, params, devices) as m:
+        st, done = m.render_passes(0, passes, SEED)
+        assert st == capi.SUCCESS and done == passes
+        total = m.reduce_sum()
+        m.render_passes(passes, len(devices), SEED)
+        more = m.reduce_sum()
+    with capi.Context(scene, params) as ctx:
+        ctx.render_passes(0, passes, SEED)
+        ref = ctx.read_sum()
+        ctx.render_passes(passes, len(devices), SEED)
+        ref_more = ctx.read_sum()
+    assert ref.sum() > 0
+    assert np.allclose(total, ref, rtol=1e-12, atol=1e-12)
+    assert np.allclose(more, ref_more, rtol=1e-12, atol=1e-12)

@@ -35,3 +35,11 @@ with hostapi.Engine(sc, options=opt) as eng:
     assert eng.render_passes(nb) == 0
     dt = time.perf_counter() - t
     print(f"batched, sum resident on the device: {npix * nb / dt / 1e6:.1f} Mpaths/s")
+
+# the loop of the reference's engine around the URenderer subclass of host/reference_adapter/ (same calls, timed in C++)
+lib = hostapi.load_library()
+import ctypes as C
+for copy, what in ((1, "with the engine's own copy of the previous sum (uengine.cpp:153-156)"), (0, "renderer alone")):
+    n = 64 if npix < (1 << 20) else 32
+    sec = lib.uhip_adapter_pass_rate(C.byref(sc.desc), C.byref(params), 0, n // 2, n, 8, copy)
+    print(f"adapter loop, {what}: {npix * n / sec / 1e6:.1f} Mpaths/s ({sec / n * 1e3:.2f} ms per pass)")

@@ -2,7 +2,10 @@
 """Turns a PMC summary (tools/pmc_summary.py) into an entry of profiles/traffic.json: HBM bytes per launch of
 every rendering kernel (the non-counting instantiation, `<false>` or `<false, placement>`) for ONE configuration.
 
-  traffic_from_pmc.py <summary.json> <config> [profiles/traffic.json]
+  traffic_from_pmc.py <summary.json> <config> [profiles/traffic.json] [bench.json of the same command]
+
+The bench line of the profiled command tells how many pixel-samples one batch held ("batch": {"pixel_samples"}); it is
+stored as _batch_pixel_samples, so that bytes per launch can be related to pixel-samples.
 
 The file maps configuration -> kernel -> bytes per launch; other configurations' entries are kept.
 
@@ -20,6 +23,7 @@ import sys
 def main():
     src, config = sys.argv[1], sys.argv[2]
     dst = sys.argv[3] if len(sys.argv) > 3 else "profiles/traffic.json"
+    bench = sys.argv[4] if len(sys.argv) > 4 else None
     d = json.load(open(src))
     out, detail = {}, {}
     for name, c in d.items():
@@ -33,6 +37,9 @@ def main():
         detail[k] = {"dispatches": n, "FETCH_SIZE_KiB_per_launch": fetch_kib, "WRITE_SIZE_KiB_per_launch": write_kib,
                      "uncorrected_bytes_per_launch": (fetch_kib + write_kib) * 1024.0}
     out["_detail"] = detail
+    if bench:
+        line = [l for l in open(bench).read().strip().splitlines() if l.startswith("{")][-1]
+        out["_batch_pixel_samples"] = json.loads(line)["batch"]["pixel_samples"]
     out["_formula"] = "(2*FETCH_SIZE + WRITE_SIZE) * 1024 bytes per launch; FETCH doubled for gfx950 (upper bound for <=64-B requests)"
     try:
         allc = json.load(open(dst))
