@@ -282,6 +282,7 @@ def main():
     ap.add_argument("--pipeline", type=int, default=0)
     ap.add_argument("--passes-in-flight", type=int, default=0)
     ap.add_argument("--max-path-vertices", type=int, default=0, help="cap on the vertices of a subpath (0 = the library's default, 32)")
+    ap.add_argument("--dense-vertex-slots", type=int, default=0, help="vertex slots stored for every subpath (0 = the library's default, 16)")
     ap.add_argument("--wavefront-depth", type=int, default=0, help="bounces run as wavefront launches (0 = default)")
     ap.add_argument("--streams", type=int, default=0, help="batches in flight on separate streams (0 = default)")
     ap.add_argument("--batch-pixel-samples", type=int, default=0, help="sub-pass batches of this many pixels (0 = whole passes)")
@@ -338,6 +339,7 @@ def main():
     opt.pipeline = args.pipeline
     opt.passes_in_flight = args.passes_in_flight
     opt.max_path_vertices = args.max_path_vertices
+    opt.dense_vertex_slots = args.dense_vertex_slots
     opt.wavefront_depth = args.wavefront_depth
     opt.streams = args.streams
     opt.batch_pixel_samples = args.batch_pixel_samples

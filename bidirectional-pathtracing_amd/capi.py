@@ -61,7 +61,8 @@ class Options(C.Structure):
     _fields_ = [("max_path_vertices", C.c_uint32), ("passes_in_flight", C.c_uint32), ("accel", C.c_uint32),
                 ("collect_stats", C.c_uint32), ("pipeline", C.c_uint32),
                 ("wavefront_depth", C.c_uint32), ("streams", C.c_uint32), ("batch_pixel_samples", C.c_uint32),
-                ("pass_slots", C.c_uint32), ("traversal_stack_entries", C.c_uint32)]
+                ("pass_slots", C.c_uint32), ("traversal_stack_entries", C.c_uint32),
+                ("dense_vertex_slots", C.c_uint32), ("vertex_pool_pages", C.c_uint32)]
 
 
 RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3)])

@@ -125,6 +125,8 @@ struct ubdpt_context {
     double* d_staging = nullptr;  // interleaved, npix * 3
     double* h_staging = nullptr;  // pinned host mirror of d_staging, allocated on first use (read-backs that add into the caller's buffer)
     uint64_t cap_paths = 0;       // path slots allocated per batch lane
+    uint32_t dense_slots = 0;     // vertex slots stored for every subpath (the rest come from a pool of pages)
+    uint32_t pages_per_k = 0;     // pool size: pages per 1024 subpaths of a batch
     uint32_t passes_in_flight = 1;
     uint32_t wf_depth = 8;        // bounces run as wavefront launches before the tail loop
     uint64_t ovf_threads = 0;     // path slots of a lane, rounded up to whole workgroups
@@ -152,6 +154,7 @@ struct ubdpt_context {
         uint64_t* d_ray_pairs = nullptr;
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
+        uint32_t* d_pool_next = nullptr;  // [0] eye, [1] light: pages of the deep vertex slots handed out in the current batch
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
         // one marker event per enqueued batch with pending.size() at that point: waiting for the oldest marker
         // bounds the host's lead over the device without draining the other lanes
@@ -184,6 +187,7 @@ struct ubdpt_context {
     std::vector<TimedLaunch> pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> event_pool;
     uint64_t stack_overflows = 0;
+    uint64_t pool_overflows = 0;   // subpaths that found the pool of deep vertex slots empty
 
     hipError_t last_hip = hipSuccess;
 
@@ -277,7 +281,7 @@ struct ubdpt_context {
     void freeLanes() {
         for (auto& b : lanes) {
             if (b.stream) hipStreamSynchronize(b.stream);
-            hipFree(b.E.v); hipFree(b.E.count); hipFree(b.L.v); hipFree(b.L.count);
+            hipFree(b.E.v); hipFree(b.E.count); hipFree(b.E.page_tab); hipFree(b.L.v); hipFree(b.L.count); hipFree(b.L.page_tab); hipFree(b.d_pool_next);
             hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
             hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_ray_pairs); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
@@ -294,11 +298,17 @@ constexpr uint64_t kMaxGridLanes = 2048ull * 256;  // lanes of the largest grid 
 #define HIPCK(ctx, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { (ctx)->last_hip = e_; \
     fprintf(stderr, "ubdpt: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return UBDPT_HIP_ERROR; } } while (0)
 
-// (silent: the caller retries with smaller batches when the memory does not suffice, and reports the failure that remains)
-int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv) {
+// Vertex storage of one kind of subpath for batches of n pixel-samples: `dense` slots for every subpath, then the
+// pool's pages, in one allocation; the page table; (silent: the caller retries with smaller batches when the memory does
+// not suffice, and reports the failure that remains)
+int allocStore(ubdpt_context* c, PathStore& P, uint64_t n, uint32_t maxv, uint32_t dense, uint32_t pool_pages, uint32_t* pool_next) {
     P.n = n; P.maxv = maxv; P.count_stride = 1;
-    hipError_t e = hipMalloc((void**)&P.v, sizeof(double) * kVertexDoubles * maxv * n);
+    P.dense = dense; P.pool_pages = pool_pages; P.cap = n; P.pool_next = pool_next;
+    P.pool_off = (uint64_t)kVertexDoubles * dense * n;
+    const uint32_t levels = dense < maxv ? (maxv - dense + kPageSlots - 1) / kPageSlots : 0;
+    hipError_t e = hipMalloc((void**)&P.v, sizeof(double) * (P.pool_off + (uint64_t)kVertexDoubles * kPageSlots * pool_pages));
     if (e == hipSuccess) e = hipMalloc((void**)&P.count, sizeof(uint32_t) * n);
+    if (e == hipSuccess) e = hipMalloc((void**)&P.page_tab, sizeof(uint32_t) * std::max<uint64_t>(1, (uint64_t)levels * n));
     if (e != hipSuccess) { c->last_hip = e; return UBDPT_HIP_ERROR; }
     return UBDPT_SUCCESS;
 }
@@ -475,6 +485,7 @@ int fetchCounters(ubdpt_context* c) {
             c->stats.bvh_nodes_visited += h[C_NODES]; c->stats.prims_tested += h[C_PRIMS]; c->stats.capped_subpaths += h[C_CAPPED];
         }
         c->stack_overflows += h[C_STACK_OVERFLOW];
+        c->pool_overflows += h[C_POOL_OVERFLOW];
     }
     return UBDPT_SUCCESS;
 }
@@ -545,7 +556,16 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         // kQueuePerPath entries, two carry and hit records, queue words; the per-path kernels of pipeline 1 also need an
         // overflow stack per pixel-sample, the wavefront kernels one per lane of their largest grid)
         const bool wavefront = c->opt.pipeline == 0;
-        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * c->opt.max_path_vertices * 2 + 8 +
+        // vertex slots: the first `dense` of every subpath, the rest in pages from a pool (paths.h)
+        const uint32_t maxv = c->opt.max_path_vertices;
+        uint32_t dense = c->opt.dense_vertex_slots ? c->opt.dense_vertex_slots : 16;
+        dense = (dense + kPageSlots - 1) / kPageSlots * kPageSlots;
+        if (dense >= maxv) dense = maxv;
+        const uint32_t page_levels = dense < maxv ? (maxv - dense + kPageSlots - 1) / kPageSlots : 0;
+        const uint32_t pages_per_k = dense < maxv ? (c->opt.vertex_pool_pages ? c->opt.vertex_pool_pages : 128u) : 0u;
+        c->dense_slots = dense; c->pages_per_k = pages_per_k;
+        uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * dense * 2 +
+                            (uint64_t)(sizeof(double) * kVertexDoubles) * kPageSlots * pages_per_k * 2 / 1024 + 8ull * page_levels + 8 +
                             kQueuePerPath * (8 + 8 + 8 + sizeof(double) * kRayDoubles + 1) +
                             2 * sizeof(double) * (kCarryDoubles + kHitDoubles) + 16 + (wavefront ? 0 : 4ull * kOverflowStack);
         const uint64_t lane_fixed = wavefront ? 4ull * kOverflowStack * kMaxGridLanes : 0;
@@ -556,7 +576,8 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             // 16 to 32 passes); a scene in HBM gains with every pass the memory holds (2 M triangles at 1080p: 2 / 3 / 4
             // passes per batch 266 / 279 / 286 Mpaths/s), because every launch of its ray tracing kernels ends with the
             // drain of its longest rays
-            uint64_t target = sceneLdsLevel(c->S) == 2 ? 1ull << 22 : 1ull << 23;
+            // (with the deep vertex slots in a pool six 1080p passes fit a lane: 2 x 4 / 2 x 6 / 2 x 8 passes 303 / 313 / 314)
+            uint64_t target = sceneLdsLevel(c->S) == 2 ? 1ull << 22 : 3ull << 22;
             pif = (uint32_t)((target + c->npix - 1) / c->npix);
             if (pif < 1) pif = 1;
             if (pif > 64) pif = 64;
@@ -615,8 +636,11 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         for (auto& b : c->lanes) {
             ck(hipStreamCreate(&b.stream));
             if (st != UBDPT_SUCCESS) break;
-            if ((st = allocStore(c, b.E, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
-            if ((st = allocStore(c, b.L, c->cap_paths, c->opt.max_path_vertices)) != UBDPT_SUCCESS) break;
+            ck(hipMalloc((void**)&b.d_pool_next, 2 * sizeof(uint32_t)));
+            if (st != UBDPT_SUCCESS) break;
+            const uint32_t pool_pages = c->pages_per_k ? (uint32_t)std::max<uint64_t>(64, c->cap_paths * c->pages_per_k / 1024) : 0u;
+            if ((st = allocStore(c, b.E, c->cap_paths, c->opt.max_path_vertices, c->dense_slots, pool_pages, b.d_pool_next)) != UBDPT_SUCCESS) break;
+            if ((st = allocStore(c, b.L, c->cap_paths, c->opt.max_path_vertices, c->dense_slots, pool_pages, b.d_pool_next + 1)) != UBDPT_SUCCESS) break;
             uint64_t n2 = 2 * c->cap_paths;
             ck(hipMalloc((void**)&b.d_ovf, sizeof(int32_t) * kOverflowStack * c->ovf_lanes));
             ck(hipMalloc((void**)&b.d_pairs, sizeof(uint64_t) * c->pair_capacity));
@@ -625,7 +649,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
             ck(hipMalloc((void**)&b.d_wf_hit, sizeof(double) * kHitDoubles * n2));
             ck(hipMalloc((void**)&b.d_vis_pairs, sizeof(uint64_t) * c->pair_capacity));
             ck(hipMalloc((void**)&b.d_vis_count, sizeof(uint32_t)));
-            ck(hipMalloc((void**)&b.d_ray_count, 3 * sizeof(uint32_t)));
+            ck(hipMalloc((void**)&b.d_ray_count, 4 * sizeof(uint32_t)));
             if (c->opt.pipeline == 0) {
                 ck(hipMalloc((void**)&b.d_rays, sizeof(double) * kRayDoubles * c->pair_capacity));
                 ck(hipMalloc((void**)&b.d_ray_flag, c->pair_capacity));
@@ -687,6 +711,14 @@ int ubdpt_destroy(ubdpt_context* c) {
 // A ray whose traversal stack was full dropped a subtree: whatever was computed with it may miss a hit.
 // The call that finds the counter set fails; the counter is cleared so that the context stays usable.
 static int reportStackOverflows(ubdpt_context* c) {
+    if (c->pool_overflows) {
+        fprintf(stderr, "ubdpt: %llu subpaths needed vertex slots beyond the first %u when the pool of pages for them was empty; the "
+                "result of this call is not valid (raise ubdpt_options.vertex_pool_pages, now %u per 1024 subpaths, or set "
+                "dense_vertex_slots = max_path_vertices)\n", (unsigned long long)c->pool_overflows, c->dense_slots, c->pages_per_k);
+        c->pool_overflows = 0;
+        c->stack_overflows = 0;
+        return UBDPT_ERROR;
+    }
     if (!c->stack_overflows) return UBDPT_SUCCESS;
     fprintf(stderr, "ubdpt: traversal stack overflow in %llu waves or rays; the result of this call is not valid\n",
             (unsigned long long)c->stack_overflows);
@@ -841,6 +873,7 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
             A.counters = c->d_counters + kernel * kNumCounters;
             c->beginTimedLane(B, kernel, u); launch(); c->endTimedLane(B);
         };
+        HIPCK(c, hipMemsetAsync(B.d_pool_next, 0, 2 * sizeof(uint32_t), sm));
         if (pl == 0) {
             HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
             A.ovf_stride = pstride;
@@ -852,7 +885,7 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
             run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
             HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
             HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
-            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 3 * sizeof(uint32_t), sm));
+            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 4 * sizeof(uint32_t), sm));
             run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, pblocks, stats, sm); });
             if (sceneLdsLevel(A.S) == 2) {
                 run(K_RAYS_VISIBLE, units, [&] { launchPairVisibleLds(A, pblocks, stats, sm); });
@@ -1217,8 +1250,8 @@ int ubdpt_connection_probe(ubdpt_context* c, const ubdpt_path_vertex* eye, uint3
     ubdpt_path_vertex* d_eye = reinterpret_cast<ubdpt_path_vertex*>(d);
     ubdpt_path_vertex* d_light = d_eye + n_eye;
     PathStore E{}, L{};
-    E.v = reinterpret_cast<double*>(d + in_bytes); E.n = 1; E.maxv = n_eye; E.count_stride = 1;
-    L.v = E.v + (size_t)kVertexDoubles * n_eye; L.n = 1; L.maxv = n_light; L.count_stride = 1;
+    E.v = reinterpret_cast<double*>(d + in_bytes); E.n = 1; E.maxv = n_eye; E.count_stride = 1; E.dense = n_eye; E.cap = 1;
+    L.v = E.v + (size_t)kVertexDoubles * n_eye; L.n = 1; L.maxv = n_light; L.count_stride = 1; L.dense = n_light; L.cap = 1;
     E.count = reinterpret_cast<uint32_t*>(d + in_bytes + store_bytes);
     L.count = E.count + 8;
     ubdpt_connection* d_out = reinterpret_cast<ubdpt_connection*>(d + in_bytes + store_bytes + 64);

@@ -27,18 +27,50 @@ enum { F_POS = 0, F_PL = 3, F_PE = 4, F_OBJFLAGS = 5, F_TEX = 6, F_NG = 9, F_NS 
 constexpr uint32_t kMaskedVertices = 24;
 DEV uint32_t specularBit(uint32_t k, bool specular) { return (specular && k < kMaskedVertices) ? (1u << (8 + k)) : 0u; }
 
-struct PathStore {
-    double* v;        // records of kVertexDoubles doubles
+// The first `dense` slots of every subpath are stored densely ([slot][path]). Few subpaths get past them (on box scenes
+// of diffuse and glass surfaces 0.4 to 1.6 % reach slot 8, 1 in 10 000 slot 16), so the slots from `dense` on are not
+// laid out for every subpath: they live in pages of kPageSlots consecutive slots of ONE subpath, handed out from a pool
+// (one atomic) when a subpath gets there, and found through a page table ([level][path], 4 bytes per entry). A batch whose
+// subpaths need more pages than the pool holds cannot be completed: the subpath that finds the pool empty ends there, a
+// counter is raised, and the call that rendered the batch fails (see api.cpp), as it does for a full traversal stack.
+constexpr uint32_t kPageSlots = 8;
+
+// PAGED = false: a view of the same store for code that only touches the dense slots (the connection evaluation of
+// pairs whose end vertices lie in them: its record addresses are then plain arithmetic, which keeps that kernel at two
+// waves per SIMD; with the page lookup in every address it needs all 512 registers of a lane).
+template <bool PAGED>
+struct PathStoreT {
+    double* v;        // records of kVertexDoubles doubles: the dense slots, then the pool's pages
     uint32_t* count;  // count word of subpath i at count[i * count_stride]
-    uint64_t n;
+    uint64_t n;       // subpaths of the batch (stride of a dense slot)
     uint32_t maxv;
     uint32_t count_stride;
+    uint32_t dense;       // slots stored densely: maxv, or a multiple of kPageSlots below it
+    uint32_t pool_pages;  // pages in the pool
+    uint64_t pool_off;    // index in v of the pool's first double
+    uint64_t cap;         // subpaths the page table is laid out for (stride of a level)
+    uint32_t* page_tab;   // [level][cap]: page of subpath i for slots dense + level * kPageSlots ..
+    uint32_t* pool_next;  // pages handed out in this batch; zeroed before every batch
 
-#ifdef UBDPT_PATH_MAJOR
-    DEV uint64_t rec(uint32_t slot, uint64_t i) const { return (i * maxv + slot) * kVertexDoubles; }
-#else
-    DEV uint64_t rec(uint32_t slot, uint64_t i) const { return ((uint64_t)slot * n + i) * kVertexDoubles; }
-#endif
+    DEV uint64_t rec(uint32_t slot, uint64_t i) const {
+        if (!PAGED || slot < dense) return ((uint64_t)slot * n + i) * kVertexDoubles;
+        const uint32_t d = slot - dense;
+        const uint32_t page = page_tab[(uint64_t)(d / kPageSlots) * cap + i];
+        return pool_off + ((uint64_t)page * kPageSlots + d % kPageSlots) * kVertexDoubles;
+    }
+    // Before slot `slot` of subpath i is written for the first time: takes a page from the pool when the slot opens
+    // one. False: the pool is empty.
+    DEV bool openSlot(uint32_t slot, uint64_t i) const {
+        if (slot < dense) return true;
+        const uint32_t d = slot - dense;
+        if (d % kPageSlots != 0) return true;
+        const uint32_t page = atomicAdd(pool_next, 1u);
+        if (page >= pool_pages) return false;
+        page_tab[(uint64_t)(d / kPageSlots) * cap + i] = page;
+        return true;
+    }
+    // pointer to the record of a slot: callers that read several fields of one vertex look the record up once
+    DEV double* rp(uint32_t slot, uint64_t i) const { return v + rec(slot, i); }
     DEV uint64_t at(int f, uint32_t slot, uint64_t i) const { return rec(slot, i) + (uint64_t)f; }
     // object index and flags (bits 0..7 = lobe + 1, bit 8 = specular) share one 8-byte field
     DEV int32_t* oflag(uint32_t slot, uint64_t i) const { return (int32_t*)(v + rec(slot, i) + F_OBJFLAGS); }
@@ -65,6 +97,21 @@ struct PathStore {
     }
     DEV int lobe(uint32_t slot, uint64_t i) const { return (flg(slot, i) & 0xff) - 1; }
 };
+using PathStore = PathStoreT<true>;
+using DensePathStore = PathStoreT<false>;
+static_assert(sizeof(PathStore) == sizeof(DensePathStore), "the dense view has the fields of the store");
+DEV DensePathStore denseView(const PathStore& P) {
+    DensePathStore d;
+    d.v = P.v; d.count = P.count; d.n = P.n; d.maxv = P.maxv; d.count_stride = P.count_stride; d.dense = P.dense;
+    d.pool_pages = P.pool_pages; d.pool_off = P.pool_off; d.cap = P.cap; d.page_tab = P.page_tab; d.pool_next = P.pool_next;
+    return d;
+}
+
+// fields of a record found through PathStore::rp
+DEV d3 rld3(const double* r, int f) { return mk3(r[f], r[f + 1], r[f + 2]); }
+DEV int32_t robj(const double* r) { return reinterpret_cast<const int32_t*>(r + F_OBJFLAGS)[0]; }
+DEV int32_t rflg(const double* r) { return reinterpret_cast<const int32_t*>(r + F_OBJFLAGS)[1]; }
+DEV bool rspecular(const double* r) { return (rflg(r) >> 8) & 1; }
 
 // A vertex held in registers while it is being built.
 struct Vertex {
@@ -78,15 +125,21 @@ struct Vertex {
 // A specular vertex is never the end of a connection (ubdptrenderer.cpp:604): all that is ever read
 // of it are the fields of line 0 (position for the neighbours' directions, the two pdfs and the flag
 // for the MIS walks), so only that line is written.
-DEV void storeVertex(const PathStore& P, uint32_t slot, uint64_t i, const Vertex& x) {
-    P.st3(F_POS, slot, i, x.sp.pos);
-    P.st(F_PL, slot, i, x.p_light_A); P.st(F_PE, slot, i, x.p_eye_A);
-    P.setObjFlags(slot, i, x.sp.object, ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0));
-    P.st(F_TEX, slot, i, x.tex.x); P.st(F_TEX + 1, slot, i, x.tex.y);
+template <class ST>
+DEV void storeVertex(const ST& P, uint32_t slot, uint64_t i, const Vertex& x) {
+    double* r = P.rp(slot, i);
+    r[F_POS] = x.sp.pos.x; r[F_POS + 1] = x.sp.pos.y; r[F_POS + 2] = x.sp.pos.z;
+    r[F_PL] = x.p_light_A; r[F_PE] = x.p_eye_A;
+    int32_t* of = reinterpret_cast<int32_t*>(r + F_OBJFLAGS);
+    of[0] = x.sp.object; of[1] = ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0);
+    r[F_TEX] = x.tex.x; r[F_TEX + 1] = x.tex.y;
     if (x.specular) return;
-    P.st(F_TEX + 2, slot, i, x.tex.z);
-    P.st3(F_NG, slot, i, x.sp.Ng); P.st3(F_NS, slot, i, x.sp.Ns);
-    P.st3(F_TS, slot, i, x.sp.Ts); P.st3(F_BS, slot, i, x.sp.Bs); P.st3(F_A, slot, i, x.a);
+    r[F_TEX + 2] = x.tex.z;
+    r[F_NG] = x.sp.Ng.x; r[F_NG + 1] = x.sp.Ng.y; r[F_NG + 2] = x.sp.Ng.z;
+    r[F_NS] = x.sp.Ns.x; r[F_NS + 1] = x.sp.Ns.y; r[F_NS + 2] = x.sp.Ns.z;
+    r[F_TS] = x.sp.Ts.x; r[F_TS + 1] = x.sp.Ts.y; r[F_TS + 2] = x.sp.Ts.z;
+    r[F_BS] = x.sp.Bs.x; r[F_BS + 1] = x.sp.Bs.y; r[F_BS + 2] = x.sp.Bs.z;
+    r[F_A] = x.a.x; r[F_A + 1] = x.a.y; r[F_A + 2] = x.a.z;
 }
 
 // The few fields of the last stored vertex that the subpath loop keeps in registers.
@@ -98,7 +151,8 @@ struct Tail {
 
 // s0sample (uengine/ubdptrenderer.cpp:156-222). `n` = subpath.size(), `cur` = subpath.back(),
 // `prev_specular` = subpath[n-2].specular; earlier vertices are read from the store.
-DEV d3 s0sample(const DScene& S, const PathStore& E, uint64_t i, uint32_t n, const Tail& cur, bool prev_specular,
+template <class ST>
+DEV d3 s0sample(const DScene& S, const ST& E, uint64_t i, uint32_t n, const Tail& cur, bool prev_specular,
                 const Vertex& ev) {
     if (ev.sp.object < 0) return mk3(0, 0, 0);
     const DObject& e = S.objects[ev.sp.object];
@@ -122,8 +176,9 @@ DEV d3 s0sample(const DScene& S, const PathStore& E, uint64_t i, uint32_t n, con
     }
     if (n > 2)
         for (int v = (int)n - 2; v > 0; v--) {
-            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
-            if (E.specular(v, i)) continue;
+            const double* r = E.rp(v, i);
+            ratio *= r[F_PL] / r[F_PE];
+            if (rspecular(r)) continue;
             if (E.specular(v - 1, i)) continue;
             w += ratio * ratio;
         }
@@ -165,23 +220,27 @@ struct ConnVertex {
     int lobe;
     bool specular;
 };
-DEV void loadConn(const PathStore& P, uint32_t slot, uint64_t i, ConnVertex& c) {
-    c.pos = P.ld3(F_POS, slot, i); c.Ng = P.ld3(F_NG, slot, i); c.Ns = P.ld3(F_NS, slot, i);
-    c.Ts = P.ld3(F_TS, slot, i);   c.Bs = P.ld3(F_BS, slot, i); c.a = P.ld3(F_A, slot, i);
-    c.p_light_A = P.ld(F_PL, slot, i); c.p_eye_A = P.ld(F_PE, slot, i);
-    c.tex = P.ld3(F_TEX, slot, i);
-    c.object = P.obj(slot, i);
-    int f = P.flg(slot, i);
+template <class ST>
+DEV void loadConn(const ST& P, uint32_t slot, uint64_t i, ConnVertex& c) {
+    const double* r = P.rp(slot, i);
+    c.pos = rld3(r, F_POS); c.Ng = rld3(r, F_NG); c.Ns = rld3(r, F_NS);
+    c.Ts = rld3(r, F_TS);   c.Bs = rld3(r, F_BS); c.a = rld3(r, F_A);
+    c.p_light_A = r[F_PL]; c.p_eye_A = r[F_PE];
+    c.tex = rld3(r, F_TEX);
+    c.object = robj(r);
+    int f = rflg(r);
     c.lobe = (f & 0xff) - 1;
     c.specular = (f >> 8) & 1;
 }
 // The lens vertex (slot 0 of an eye subpath): only its position varies, so only line 0 of its record is stored
 // and the rest is made here (the values computeEyeSubpath gives it, ubdptrenderer.cpp:231-246).
 DEV d3 lensNormal(const DScene& S) { return transformVector(S.invV, mk3(0, 0, 1)); }
-DEV void loadConnEye(const DScene& S, const PathStore& E, uint32_t slot, uint64_t i, ConnVertex& c) {
+template <class ST>
+DEV void loadConnEye(const DScene& S, const ST& E, uint32_t slot, uint64_t i, ConnVertex& c) {
     if (slot != 0) { loadConn(E, slot, i, c); return; }
-    c.pos = E.ld3(F_POS, 0, i);
-    c.p_light_A = E.ld(F_PL, 0, i); c.p_eye_A = E.ld(F_PE, 0, i);
+    const double* r = E.rp(0, i);
+    c.pos = rld3(r, F_POS);
+    c.p_light_A = r[F_PL]; c.p_eye_A = r[F_PE];
     c.Ng = c.Ns = lensNormal(S);
     c.Ts = transformVector(S.invV, mk3(1, 0, 0));
     c.Bs = transformVector(S.invV, mk3(0, 1, 0));
@@ -189,11 +248,14 @@ DEV void loadConnEye(const DScene& S, const PathStore& E, uint32_t slot, uint64_
     c.tex = mk3(0, 0, 0);
     c.object = -1; c.lobe = -1; c.specular = false;
 }
-DEV void storeLensVertex(const PathStore& E, uint64_t i, const Vertex& x) {
-    E.st3(F_POS, 0, i, x.sp.pos);
-    E.st(F_PL, 0, i, x.p_light_A); E.st(F_PE, 0, i, x.p_eye_A);
-    E.setObjFlags(0, i, x.sp.object, ((x.sp.lobe + 1) & 0xff));
-    E.st(F_TEX, 0, i, 0.0); E.st(F_TEX + 1, 0, i, 0.0);
+template <class ST>
+DEV void storeLensVertex(const ST& E, uint64_t i, const Vertex& x) {
+    double* r = E.rp(0, i);
+    r[F_POS] = x.sp.pos.x; r[F_POS + 1] = x.sp.pos.y; r[F_POS + 2] = x.sp.pos.z;
+    r[F_PL] = x.p_light_A; r[F_PE] = x.p_eye_A;
+    int32_t* of = reinterpret_cast<int32_t*>(r + F_OBJFLAGS);
+    of[0] = x.sp.object; of[1] = ((x.sp.lobe + 1) & 0xff);
+    r[F_TEX] = 0.0; r[F_TEX + 1] = 0.0;
 }
 
 DEV Frame frameOf(const ConnVertex& c) { Frame f; f.Ng = c.Ng; f.Ns = c.Ns; f.Ts = c.Ts; f.Bs = c.Bs; return f; }
@@ -240,20 +302,23 @@ struct WalkAhead {
     double plE[kWalkAhead], peE[kWalkAhead], plL[kWalkAhead], peL[kWalkAhead];
     uint32_t specE, specL;  // bit k: the vertex of step k is specular
 };
-DEV void loadWalkAhead(const PathStore& L, const PathStore& E, uint64_t i, uint32_t s, uint32_t t, WalkAhead& a) {
+template <class ST>
+DEV void loadWalkAhead(const ST& L, const ST& E, uint64_t i, uint32_t s, uint32_t t, WalkAhead& a) {
     a.specE = a.specL = 0;
 #pragma unroll
     for (int k = 0; k < kWalkAhead; k++) {
         int v = (int)t - 2 - k;
         uint32_t vc = v > 0 ? (uint32_t)v : 0u;
-        a.plE[k] = E.ld(F_PL, vc, i);
-        a.peE[k] = E.ld(F_PE, vc, i);
-        a.specE |= ((v > 0) & ((E.flg(vc, i) >> 8) & 1)) ? (1u << k) : 0u;
+        const double* r = E.rp(vc, i);
+        a.plE[k] = r[F_PL];
+        a.peE[k] = r[F_PE];
+        a.specE |= ((v > 0) & ((rflg(r) >> 8) & 1)) ? (1u << k) : 0u;
         v = (int)s - 2 - k;
         vc = v > 0 ? (uint32_t)v : 0u;
-        a.plL[k] = L.ld(F_PL, vc, i);
-        a.peL[k] = L.ld(F_PE, vc, i);
-        a.specL |= ((v > 0) & ((L.flg(vc, i) >> 8) & 1)) ? (1u << k) : 0u;
+        r = L.rp(vc, i);
+        a.plL[k] = r[F_PL];
+        a.peL[k] = r[F_PE];
+        a.specL |= ((v > 0) & ((rflg(r) >> 8) & 1)) ? (1u << k) : 0u;
     }
 }
 
@@ -261,7 +326,8 @@ DEV void loadWalkAhead(const PathStore& L, const PathStore& E, uint64_t i, uint3
 // specular (ubdptrenderer.cpp:604), and every non-specular surface vertex carries the Lambertian
 // lobe, whose value (tex/pi) and pdf (1/pi) are constants once the same-side tests pass.
 // Returns false when the connection contributes nothing; otherwise c (connection factor) and w (MIS weight).
-DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, const ConnVertex& vl,
+template <class ST>
+DEV bool connectLambert(const DScene& S, const ST& L, const ST& E, uint64_t i, const ConnVertex& vl,
                         const ConnVertex& ve, uint32_t s, uint32_t t, d3 lprev, d3 eprev, const WalkAhead& wa, d3& c,
                         double& w) {
     const uint32_t specE = wa.specE, specL = wa.specL;
@@ -315,8 +381,9 @@ DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E,
             w += ratio * ratio;
         }
         for (; v > 0; v--) {
-            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
-            if (E.specular(v, i)) continue;
+            const double* r = E.rp(v, i);
+            ratio *= r[F_PL] / r[F_PE];
+            if (rspecular(r)) continue;
             if (v - 1 > 0 && E.specular(v - 1, i)) continue;
             w += ratio * ratio;
         }
@@ -339,8 +406,9 @@ DEV bool connectLambert(const DScene& S, const PathStore& L, const PathStore& E,
             w += ratio * ratio;
         }
         for (; v >= 0; v--) {
-            ratio *= L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
-            if (L.specular(v, i)) continue;
+            const double* r = L.rp(v, i);
+            ratio *= r[F_PE] / r[F_PL];
+            if (rspecular(r)) continue;
             if (v > 1)
                 if (L.specular(v - 1, i)) continue;
             w += ratio * ratio;
@@ -415,8 +483,9 @@ DEV double misWeight(const DScene& S, const SL& L, const SE& E, uint64_t i, cons
     }
     if (t > 2)
         for (int v = (int)t - 2; v > 0; v--) {
-            ratio *= E.ld(F_PL, v, i) / E.ld(F_PE, v, i);
-            if (E.specular(v, i)) continue;
+            const double* r = E.rp(v, i);
+            ratio *= r[F_PL] / r[F_PE];
+            if (rspecular(r)) continue;
             if (E.specular(v - 1, i)) continue;
             w += ratio * ratio;
         }
@@ -437,8 +506,9 @@ DEV double misWeight(const DScene& S, const SL& L, const SE& E, uint64_t i, cons
         w += ratio * ratio;
     if (s > 1)
         for (int v = (int)s - 2; v >= 0; v--) {
-            ratio *= L.ld(F_PE, v, i) / L.ld(F_PL, v, i);
-            if (L.specular(v, i)) continue;
+            const double* r = L.rp(v, i);
+            ratio *= r[F_PE] / r[F_PL];
+            if (rspecular(r)) continue;
             if (v > 0)
                 if (L.specular(v - 1, i)) continue;
             w += ratio * ratio;

@@ -32,7 +32,7 @@ struct RenderArgs {
     uint32_t* vis_count;
     double* rays;            // shadow-ray queue, kRayDoubles per ray: origin, direction, length
     uint64_t* ray_pairs;     // the pair each ray of the queue belongs to
-    uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at; ray_count[2] = pixel-samples k_pair_enum could not queue
+    uint32_t* ray_count;     // rays in the queue; ray_count[1] = the position the persistent waves claim chunks at; ray_count[2] = pixel-samples k_pair_enum could not queue; ray_count[3] = pairs k_pair_eval put aside for its second launch (in ray_pairs)
     uint32_t* ray_head;
     uint8_t* ray_flag;       // one per ray: 1 = nothing blocks it
     uint32_t* wf_trace_q;    // [2][2n] ping-pong queues of live subpaths
@@ -63,7 +63,7 @@ void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_
 constexpr int kNumCounters = 16;
 // counters, indices into RenderArgs::counters (one block of kNumCounters words per kernel); C_MAX_STACK is a maximum, the others are sums
 enum { C_CLOSEST = 0, C_SHADOW, C_EYE_V, C_LIGHT_V, C_CONN, C_SPLAT, C_NODES, C_PRIMS, C_CAPPED, C_STACK_OVERFLOW, C_FB,
-       C_WAVE_NODES, C_WAVE_PRIMS, C_MAX_STACK, C_NUM };
+       C_WAVE_NODES, C_WAVE_PRIMS, C_MAX_STACK, C_POOL_OVERFLOW, C_NUM };
 static_assert(C_NUM <= kNumCounters, "counter block too small");
 
 void launchEye(const RenderArgs& A, bool stats, hipStream_t s);

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
             break;
         finishVertex(obj, nv, dirT);
         I = I + s0sample(S, E, gid, n, cur, prev_specular, nv);
+        if (!E.openSlot(n, gid)) { atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL); break; }
         storeVertex(E, n, gid, nv);
         smask |= specularBit(n, nv.specular);
         n++;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
                              rng(hitDim(h, DIM_SCATTER_2)), dT, p_psa, fs, nv.specular))
                 break;
             finishVertex(obj, nv, dT);
+            if (!L.openSlot(n, gid)) { atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL); break; }
             storeVertex(L, n, gid, nv);
             smask |= specularBit(n, nv.specular);
             n++;
@@ -502,7 +504,8 @@ DEV uint32_t waveInclusiveScan(uint32_t v) {
 // (ubdptrenderer.cpp:612-690) and weight (:779-844). Every load whose address depends on (i, s, t) only is issued
 // before the first use of any of them (the positions before the end vertices exist only for s, t > 1 and are only
 // used then; slot 0 is read otherwise). a = throughput product of the two end vertices. False: contributes nothing.
-DEV bool pairConnection(const DScene& S, const PathStore& L, const PathStore& E, uint64_t i, uint32_t s, uint32_t t,
+template <class ST>
+DEV bool pairConnection(const DScene& S, const ST& L, const ST& E, uint64_t i, uint32_t s, uint32_t t,
                         ConnVertex& vl, ConnVertex& ve, d3& c, double& w) {
     loadConn(L, s - 1, i, vl);
     loadConnEye(S, E, t - 1, i, ve);
@@ -519,13 +522,16 @@ DEV bool pairConnection(const DScene& S, const PathStore& L, const PathStore& E,
 
 // Second half of a connection (no ray is traced here). Returns the contribution and the pixel it belongs to;
 // false when the pair contributes nothing.
-template <bool STATS>
+// DEEP = false: s and t lie within the dense vertex slots (then so does every vertex the pair touches).
+template <bool STATS, bool DEEP>
 DEV bool pairEval(const RenderArgs& A, uint64_t i, uint32_t s, uint32_t t, Tally& ty, uint64_t& pixel, d3& value) {
     const DScene& S = A.S;
     ConnVertex vl, ve;
     d3 c;
     double w;
-    const bool ok = pairConnection(S, A.L, A.E, i, s, t, vl, ve, c, w);
+    bool ok;
+    if (DEEP) ok = pairConnection(S, A.L, A.E, i, s, t, vl, ve, c, w);
+    else      ok = pairConnection(S, denseView(A.L), denseView(A.E), i, s, t, vl, ve, c, w);
     uint32_t tx = 0, tyy = 0;
     if (t == 1) {
         if (!t1Pixel(S, vl.pos, ve.pos, tx, tyy)) return false;
@@ -647,19 +653,30 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
     }
 }
 
-// The pixel-samples k_pair_enum could not queue: every lane runs the connection loop of its pixel-sample (shadow ray
-// included), the reference's loop structure. Launched after every k_pair_enum; the list is almost always empty.
+// What the queues could not take, after everything else of the batch: the pixel-samples k_pair_enum had no room for
+// (every lane runs the connection loop of its pixel-sample, shadow rays included, the reference's loop structure) and
+// the visible pairs with an end vertex beyond the dense vertex slots, which k_pair_eval put aside. Launched once per
+// batch; both lists are almost always empty.
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_pair_overflow(RenderArgs A) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint64_t gid0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
     const uint32_t total = A.ray_count[2];
-    if (total == 0) return;
+    const uint32_t deep_total = A.ray_count[3];
+    if (total == 0 && deep_total == 0) return;
     const PathStore& E = A.E;
     const PathStore& L = A.L;
     Stack st = makeStack(lds_stack, A.ovf, A.ovf_stride, gid0, A.ovf_cap);
     Tally ty;
+    // the visible pairs k_pair_eval put aside because an end vertex lies beyond the dense vertex slots
+    const uint64_t npix_all = (uint64_t)A.S.img_res_x * A.S.img_res_y;
+    for (uint64_t j = gid0; j < deep_total; j += nthreads) {
+        const uint64_t p = A.ray_pairs[j];
+        uint64_t pixel;
+        d3 v;
+        if (pairEval<STATS, true>(A, p >> 16, (uint32_t)((p >> 8) & 0xff), (uint32_t)(p & 0xff), ty, pixel, v)) fbAdd(A.fb, npix_all, pixel, v);
+    }
     for (uint64_t j = gid0; j < total; j += nthreads) {
         const uint64_t gid = A.wf_trace_q[j];
         const uint32_t mE = E.meta(gid), mL = L.meta(gid);
@@ -930,11 +947,6 @@ void launchWfTail(const RenderArgs& A, uint32_t depth, unsigned blocks, bool sta
 void launchPairEnum(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_enum<true>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_enum<false>, dim3(gridFor(A.E.n)), dim3(kBlock), 0, s, A);
-    // one workgroup per CU at most: the list is almost always empty, and a workgroup of this kernel needs half a SIMD's
-    // registers to start at all
-    const unsigned oblocks = blocks < 256u ? blocks : 256u;
-    if (stats) hipLaunchKernelGGL(k_pair_overflow<true>, dim3(oblocks), dim3(kBlock), 0, s, A);
-    else hipLaunchKernelGGL(k_pair_overflow<false>, dim3(oblocks), dim3(kBlock), 0, s, A);
 }
 // picks the instantiation (counting or not, object table in LDS or not) of a kernel template K<bool, uint32_t>
 #define UBDPT_LAUNCH_LDS(K, CAP, ...)                                                                          \
@@ -989,6 +1001,11 @@ void launchPairCompact(const RenderArgs& A, unsigned blocks, hipStream_t s) {
 void launchPairEval(const RenderArgs& A, unsigned blocks, bool stats, hipStream_t s) {
     if (stats) hipLaunchKernelGGL(k_pair_eval<true>, dim3(blocks), dim3(kBlock), 0, s, A);
     else hipLaunchKernelGGL(k_pair_eval<false>, dim3(blocks), dim3(kBlock), 0, s, A);
+    // what the queues could not take (k_pair_overflow): one workgroup per CU at most, the lists are almost always empty,
+    // and a workgroup of that kernel needs all registers of a SIMD to start at all
+    const unsigned oblocks = blocks < 256u ? blocks : 256u;
+    if (stats) hipLaunchKernelGGL(k_pair_overflow<true>, dim3(oblocks), dim3(kBlock), 0, s, A);
+    else hipLaunchKernelGGL(k_pair_overflow<false>, dim3(oblocks), dim3(kBlock), 0, s, A);
 }
 void launchIntersectBatch(const DScene& S, const ubdpt_ray* rays, size_t n, ubdpt_hit* hits, int32_t* ovf,
                           uint64_t ovf_stride, uint32_t ovf_cap, unsigned long long* counters, hipStream_t s) {

@@ -133,6 +133,14 @@ typedef struct ubdpt_options {
     uint32_t traversal_stack_entries; /* entries of a ray's traversal stack; 0 -> 112 (the maximum: 16 on chip, 96 in
                                    device memory). A ray that needs more makes the call that traced it return UBDPT_ERROR:
                                    a dropped subtree could hide a hit, so such a result is never handed out silently */
+    uint32_t dense_vertex_slots; /* vertex slots stored for EVERY subpath of a batch; 0 -> 16 (rounded up to a multiple of 8,
+                                   at most max_path_vertices). The slots beyond them are handed out in pages of 8 from a
+                                   pool, to the few subpaths that get that far (1 in 10 000 reaches slot 16 on box scenes
+                                   with glass): a third less memory per pixel-sample, larger batches. */
+    uint32_t vertex_pool_pages;  /* size of that pool: pages per 1024 subpaths of a batch; 0 -> 128 (one subpath in eight
+                                   can hold a page). A batch that needs more makes the call that rendered it return
+                                   UBDPT_ERROR (a truncated subpath is never handed out silently): raise this, or store
+                                   every slot densely (dense_vertex_slots = max_path_vertices). */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */
