@@ -125,21 +125,29 @@ struct Vertex {
 // A specular vertex is never the end of a connection (ubdptrenderer.cpp:604): all that is ever read
 // of it are the fields of line 0 (position for the neighbours' directions, the two pdfs and the flag
 // for the MIS walks), so only that line is written.
+// Records are written with 16-byte stores. (Marking these stores non-temporal, so that the streamed records would leave
+// the tree in the caches, was measured on a 2 M-triangle scene: the ray tracing kernels stay where they are and the
+// kernels that store slow down, generation from 3.4 to 8.6 ms per batch; plain stores stay.)
+typedef double v2d __attribute__((ext_vector_type(2)));
+DEV void st2(double* p, double a, double b) {
+    v2d v; v.x = a; v.y = b;
+    *reinterpret_cast<v2d*>(p) = v;
+}
 template <class ST>
 DEV void storeVertex(const ST& P, uint32_t slot, uint64_t i, const Vertex& x) {
     double* r = P.rp(slot, i);
-    r[F_POS] = x.sp.pos.x; r[F_POS + 1] = x.sp.pos.y; r[F_POS + 2] = x.sp.pos.z;
-    r[F_PL] = x.p_light_A; r[F_PE] = x.p_eye_A;
-    int32_t* of = reinterpret_cast<int32_t*>(r + F_OBJFLAGS);
-    of[0] = x.sp.object; of[1] = ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0);
-    r[F_TEX] = x.tex.x; r[F_TEX + 1] = x.tex.y;
+    double of;
+    {
+        int32_t w[2] = {x.sp.object, ((x.sp.lobe + 1) & 0xff) | (x.specular ? 0x100 : 0)};
+        __builtin_memcpy(&of, w, 8);
+    }
+    st2(r + 0, x.sp.pos.x, x.sp.pos.y); st2(r + 2, x.sp.pos.z, x.p_light_A); st2(r + 4, x.p_eye_A, of);
+    st2(r + 6, x.tex.x, x.tex.y);
     if (x.specular) return;
-    r[F_TEX + 2] = x.tex.z;
-    r[F_NG] = x.sp.Ng.x; r[F_NG + 1] = x.sp.Ng.y; r[F_NG + 2] = x.sp.Ng.z;
-    r[F_NS] = x.sp.Ns.x; r[F_NS + 1] = x.sp.Ns.y; r[F_NS + 2] = x.sp.Ns.z;
-    r[F_TS] = x.sp.Ts.x; r[F_TS + 1] = x.sp.Ts.y; r[F_TS + 2] = x.sp.Ts.z;
-    r[F_BS] = x.sp.Bs.x; r[F_BS + 1] = x.sp.Bs.y; r[F_BS + 2] = x.sp.Bs.z;
-    r[F_A] = x.a.x; r[F_A + 1] = x.a.y; r[F_A + 2] = x.a.z;
+    st2(r + 8, x.tex.z, x.sp.Ng.x); st2(r + 10, x.sp.Ng.y, x.sp.Ng.z);
+    st2(r + 12, x.sp.Ns.x, x.sp.Ns.y); st2(r + 14, x.sp.Ns.z, x.sp.Ts.x);
+    st2(r + 16, x.sp.Ts.y, x.sp.Ts.z); st2(r + 18, x.sp.Bs.x, x.sp.Bs.y);
+    st2(r + 20, x.sp.Bs.z, x.a.x); st2(r + 22, x.a.y, x.a.z);
 }
 
 // The few fields of the last stored vertex that the subpath loop keeps in registers.

@@ -63,18 +63,14 @@ DEV void loadCarryRay(const RenderArgs& A, uint64_t id, Ray& r) {
 }
 DEV void storeCarry(const RenderArgs& A, uint64_t id, const Carry& c) {
     double* p = A.carry + id * kCarryDoubles;
-    p[0] = c.pos.x; p[1] = c.pos.y; p[2] = c.pos.z;
-    p[3] = c.dir.x; p[4] = c.dir.y; p[5] = c.dir.z;
-    p[6] = c.p_psa;
-    p[8] = c.a.x; p[9] = c.a.y; p[10] = c.a.z;
-    p[11] = c.Ns.x; p[12] = c.Ns.y; p[13] = c.Ns.z;
-    p[14] = c.q;
-    p[15] = c.pending;
+    st2(p + 0, c.pos.x, c.pos.y); st2(p + 2, c.pos.z, c.dir.x); st2(p + 4, c.dir.y, c.dir.z);
+    p[6] = c.p_psa;   // (p[7] holds the count word)
+    st2(p + 8, c.a.x, c.a.y); st2(p + 10, c.a.z, c.Ns.x); st2(p + 12, c.Ns.y, c.Ns.z); st2(p + 14, c.q, c.pending);
 }
 DEV void storeHit(const RenderArgs& A, uint64_t id, const Closest& h) {
     double* p = A.wf_hit + id * kHitDoubles;
-    p[0] = h.d; p[1] = h.u; p[2] = h.v;
-    p[3] = __longlong_as_double((long long)(((unsigned long long)h.face << 32) | (uint32_t)h.object));
+    st2(p + 0, h.d, h.u);
+    st2(p + 2, h.v, __longlong_as_double((long long)(((unsigned long long)h.face << 32) | (uint32_t)h.object)));
 }
 DEV void loadHit(const RenderArgs& A, uint64_t id, Closest& h) {
     const double* p = A.wf_hit + id * kHitDoubles;
