@@ -657,8 +657,13 @@ __global__ __launch_bounds__(kBlock) void k_pair_enum(RenderArgs A) {
 // (every lane runs the connection loop of its pixel-sample, shadow rays included, the reference's loop structure) and
 // the visible pairs with an end vertex beyond the dense vertex slots, which k_pair_eval put aside. Launched once per
 // batch; both lists are almost always empty.
+// (Compiled for four waves per SIMD instead, 128 registers with 471 spilled, so that a workgroup of it would start wherever
+// one workgroup of the other lane's ray tracing kernels ends: 305 against 307 Mpaths/s on a 2 M-triangle scene, no gain.)
+#ifndef UBDPT_RARE_WAVES
+#define UBDPT_RARE_WAVES 1
+#endif
 template <bool STATS>
-__global__ __launch_bounds__(kBlock) void k_pair_overflow(RenderArgs A) {
+__global__ __launch_bounds__(kBlock, UBDPT_RARE_WAVES) void k_pair_overflow(RenderArgs A) {
     __shared__ int32_t lds_stack[kLdsStack * kBlock];
     const uint64_t gid0 = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;

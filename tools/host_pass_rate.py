@@ -21,14 +21,17 @@ if len(sys.argv) > 2:  # per-pass buffers of the engine's renderer (two windows 
     opt.pass_slots = int(sys.argv[2])
 with hostapi.Engine(sc, options=opt) as eng:
     assert eng.new_rendering(params) == 0
-    for _ in range(4 if opt is None else max(4, opt.pass_slots)):
+    # passes are served from windows rendered ahead: warm up over two windows, then time four, so that the timed
+    # region neither consumes work done before it nor leaves work behind
+    win = max(1, min(32, (1 << 24) // npix)) if opt is None else max(1, opt.pass_slots // 2)
+    for _ in range(2 * win):
         eng.render_pass()
     t = time.perf_counter()
-    n = 32 if npix < (1 << 20) else 24
+    n = 4 * win
     for _ in range(n):
         assert eng.render_pass() == 0
     dt = time.perf_counter() - t
-    print(f"pass-by-pass through the host buffer: {npix * n / dt / 1e6:.1f} Mpaths/s ({dt / n * 1e3:.2f} ms per pass)")
+    print(f"pass-by-pass through the host buffer (HipEngine, windows of {win}): {npix * n / dt / 1e6:.1f} Mpaths/s ({dt / n * 1e3:.2f} ms per pass)")
     nb = 256 if npix < (1 << 20) else 32
     eng.render_passes(16 if npix < (1 << 20) else 4)
     t = time.perf_counter()
