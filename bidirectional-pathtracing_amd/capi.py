@@ -111,7 +111,7 @@ EXPORTS = [
     "ubdpt_read_sum_slot_onto",
     "ubdpt_enqueue_passes_separate",
     "ubdpt_intersect_batch", "ubdpt_intersect_batch_noalloc", "ubdpt_visibility_batch", "ubdpt_get_object_info", "ubdpt_get_camera_info",
-    "ubdpt_get_image_size", "ubdpt_get_batch_info", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
+    "ubdpt_get_image_size", "ubdpt_get_batch_info", "ubdpt_get_recovery_info", "ubdpt_get_stats", "ubdpt_reset_stats", "ubdpt_bsdf_eval_batch", "ubdpt_bsdf_pdf_batch",
     "ubdpt_bsdf_scatter_batch", "ubdpt_connection_probe",
 ]
 
@@ -184,6 +184,7 @@ def load_library(path=None):
     lib.ubdpt_get_camera_info.argtypes = [vp, vp, vp, vp]
     lib.ubdpt_get_image_size.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ubdpt_get_batch_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.ubdpt_get_recovery_info.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.ubdpt_get_stats.argtypes = [vp, C.POINTER(Stats)]
     lib.ubdpt_reset_stats.argtypes = [vp]
     lib.ubdpt_connection_probe.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, vp, vp]
@@ -363,6 +364,12 @@ class Context:
         n, l, d = C.c_uint64(0), C.c_uint32(0), C.c_uint32(0)
         _check(self.lib.ubdpt_get_batch_info(self.handle, C.byref(n), C.byref(l), C.byref(d)), "ubdpt_get_batch_info")
         return n.value, l.value, d.value
+
+    def recovery_info(self):
+        """(batches that exhausted the pool of deep vertex slots and were rendered again, pixel-samples per batch now)."""
+        r, n = C.c_uint64(), C.c_uint64()
+        _check(self.lib.ubdpt_get_recovery_info(self.handle, C.byref(r), C.byref(n)), "ubdpt_get_recovery_info")
+        return r.value, n.value
 
     def stats(self):
         s = Stats()

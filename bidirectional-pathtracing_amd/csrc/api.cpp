@@ -135,6 +135,9 @@ struct ubdpt_context {
     void* noalloc_scratch = nullptr;             // device address of the static scratch array on this context's GPU
     unsigned long long* h_noalloc_counters = nullptr;  // pinned, kNumCounters words: counters of the last no-allocation call
     unsigned long long pair_capacity = 0;
+    // One call's passes as the batches see them, and one batch: pixel-samples [pos, pos + n) of the call in (pass, pixel) order
+    struct CallDesc { uint64_t first_pass = 0, pass_stride = 1, seed = 0; bool separate = false; uint32_t first_slot = 0; };
+    struct BatchDesc { CallDesc call; uint64_t pos = 0, n = 0; };
     // A batch lane owns every per-batch buffer and a stream; consecutive batches go to consecutive
     // lanes, so the narrow late stages of one batch (deep bounces, tail) overlap the wide early
     // stages of the next. The sum buffer and the counters are shared (atomics).
@@ -154,13 +157,31 @@ struct ubdpt_context {
         uint64_t* d_ray_pairs = nullptr;
         uint32_t* d_wf_trace_q = nullptr;
         uint32_t* d_wf_count = nullptr;
-        uint32_t* d_pool_next = nullptr;  // [0] eye, [1] light: pages of the deep vertex slots handed out in the current batch
+        uint32_t* d_pool_next = nullptr;  // [0] eye, [1] light: pages of the deep vertex slots asked for in the current batch; [2] the batch cannot be completed
+        double* d_fb_lane = nullptr;      // what the current batch adds to the sum buffers (fb_lane_slots planar buffers), see k_commit_batch
+        unsigned long long* d_counters = nullptr;  // and to the counters
+        uint32_t* h_result = nullptr;     // pinned ring of kResultRing x 4 words: d_pool_next as every batch left it
+        uint64_t seq = 0;                 // batches enqueued on this lane
         std::vector<TimedLaunch> pending;  // timed launches of this lane not yet folded into the statistics
         // one marker event per enqueued batch with pending.size() at that point: waiting for the oldest marker
         // bounds the host's lead over the device without draining the other lanes
-        struct Marker { hipEvent_t first; size_t second; uint64_t paths; };  // event, pending.size(), pixel-samples of the batch
+        struct Marker {   // event, pending.size(), pixel-samples of the batch as the progress counts them; the batch; where its result lands
+            hipEvent_t first; size_t second; uint64_t paths;
+            BatchDesc desc; const uint32_t* result;
+        };
         std::deque<Marker> inflight;
     };
+    static constexpr uint32_t kResultRing = 128;   // more than the batches a lane may have in flight (throttle: at most 64)
+    // Batches that could not be completed (a subpath found the pool of deep vertex slots empty): their sums were dropped on
+    // the device; they are rendered again in pieces small enough for the pool, and the batches after them are made smaller.
+    struct Failed { BatchDesc desc; uint32_t asked_eye, asked_light; };
+    std::vector<Failed> redo;
+    uint64_t batch_limit = 0;      // pixel-samples per batch from now on (<= cap_paths; lowered when a batch failed)
+    uint64_t safe_paths = 0;       // a batch of at most this many pixel-samples cannot exhaust the pool (pool pages / page levels)
+    uint32_t page_levels = 0;
+    uint32_t pool_pages = 0;
+    uint32_t fb_lane_slots = 1;    // sum buffers per lane: the passes a batch may touch when they are kept apart, else one
+    uint64_t batches_redone = 0;
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
     // ubdpt_query_progress reads these without the context mutex (an enqueue call holds that one while it waits for room on
@@ -225,37 +246,44 @@ struct ubdpt_context {
     }
     void endTimedLane(BatchLane& b) { hipEventRecord(b.pending.back().stop, b.stream); }
     std::vector<hipEvent_t> marker_pool;
-    void markBatch(BatchLane& b, uint64_t paths) {
+    void markBatch(BatchLane& b, uint64_t paths, const BatchDesc& desc, const uint32_t* result) {
         hipEvent_t ev;
         if (!marker_pool.empty()) { ev = marker_pool.back(); marker_pool.pop_back(); }
         else hipEventCreateWithFlags(&ev, hipEventDisableTiming);
         hipEventRecord(ev, b.stream);
         std::lock_guard<std::mutex> pl(progress_mu);
-        b.inflight.push_back(BatchLane::Marker{ev, b.pending.size(), paths});
+        b.inflight.push_back(BatchLane::Marker{ev, b.pending.size(), paths, desc, result});
         paths_enqueued += paths;
+    }
+    // the lane's oldest batch has finished (its marker was reached): statistics, result, marker back to the pool
+    void popFinished(BatchLane& b) {
+        auto front = b.inflight.front();
+        foldTimed(b.pending, front.second);
+        if (front.result[2]) redo.push_back(Failed{front.desc, front.result[0], front.result[1]});
+        std::lock_guard<std::mutex> pl(progress_mu);
+        b.inflight.pop_front();
+        for (auto& f : b.inflight) f.second -= front.second;
+        marker_pool.push_back(front.first);
     }
     // waits until at most max_inflight batches of the lane are unfinished
     hipError_t throttle(BatchLane& b, size_t max_inflight) {
         while (b.inflight.size() > max_inflight) {
-            auto front = b.inflight.front();
-            hipError_t e = hipEventSynchronize(front.first);
+            hipError_t e = hipEventSynchronize(b.inflight.front().first);
             if (e != hipSuccess) return e;
-            foldTimed(b.pending, front.second);
-            std::lock_guard<std::mutex> pl(progress_mu);
-            b.inflight.pop_front();
-            for (auto& f : b.inflight) f.second -= front.second;
-            marker_pool.push_back(front.first);
+            popFinished(b);
         }
         return hipSuccess;
     }
+    // takes in the batches that have finished by now, without waiting
+    void reapFinished() {
+        for (auto& b : lanes)
+            while (!b.inflight.empty() && hipEventQuery(b.inflight.front().first) == hipSuccess) popFinished(b);
+        (void)hipGetLastError();  // hipEventQuery reports "not ready" as an error status
+    }
     // after every lane stream has been synchronised
     void collectLanes() {
-        for (auto& b : lanes) {
-            foldTimed(b.pending, b.pending.size());
-            std::lock_guard<std::mutex> pl(progress_mu);
-            for (auto& f : b.inflight) marker_pool.push_back(f.first);
-            b.inflight.clear();
-        }
+        for (auto& b : lanes)
+            while (!b.inflight.empty()) popFinished(b);
     }
     void freeAll() {
         hipSetDevice(device);
@@ -282,6 +310,7 @@ struct ubdpt_context {
         for (auto& b : lanes) {
             if (b.stream) hipStreamSynchronize(b.stream);
             hipFree(b.E.v); hipFree(b.E.count); hipFree(b.E.page_tab); hipFree(b.L.v); hipFree(b.L.count); hipFree(b.L.page_tab); hipFree(b.d_pool_next);
+            hipFree(b.d_fb_lane); hipFree(b.d_counters); if (b.h_result) hipHostFree(b.h_result);
             hipFree(b.d_ovf); hipFree(b.d_pairs); hipFree(b.d_pair_count); hipFree(b.d_carry); hipFree(b.d_wf_hit);
             hipFree(b.d_vis_pairs); hipFree(b.d_vis_count); hipFree(b.d_rays); hipFree(b.d_ray_count); hipFree(b.d_ray_flag); hipFree(b.d_ray_pairs); hipFree(b.d_wf_trace_q); hipFree(b.d_wf_count);
             if (b.stream) hipStreamDestroy(b.stream);
@@ -563,11 +592,12 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         if (dense >= maxv) dense = maxv;
         const uint32_t page_levels = dense < maxv ? (maxv - dense + kPageSlots - 1) / kPageSlots : 0;
         const uint32_t pages_per_k = dense < maxv ? (c->opt.vertex_pool_pages ? c->opt.vertex_pool_pages : 128u) : 0u;
-        c->dense_slots = dense; c->pages_per_k = pages_per_k;
+        c->dense_slots = dense; c->pages_per_k = pages_per_k; c->page_levels = page_levels;
         uint64_t per_path = (uint64_t)(sizeof(double) * kVertexDoubles) * dense * 2 +
                             (uint64_t)(sizeof(double) * kVertexDoubles) * kPageSlots * pages_per_k * 2 / 1024 + 8ull * page_levels + 8 +
                             kQueuePerPath * (8 + 8 + 8 + sizeof(double) * kRayDoubles + 1) +
-                            2 * sizeof(double) * (kCarryDoubles + kHitDoubles) + 16 + (wavefront ? 0 : 4ull * kOverflowStack);
+                            2 * sizeof(double) * (kCarryDoubles + kHitDoubles) + 16 + (wavefront ? 0 : 4ull * kOverflowStack) +
+                            3 * sizeof(double);   // (the lane's sum buffers when the passes are kept apart)
         const uint64_t lane_fixed = wavefront ? 4ull * kOverflowStack * kMaxGridLanes : 0;
         auto laneBytes = [&](uint32_t passes) { return (per_path + 64) * c->npix * passes + lane_fixed; };
         uint32_t pif = c->opt.passes_in_flight;
@@ -636,9 +666,26 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         for (auto& b : c->lanes) {
             ck(hipStreamCreate(&b.stream));
             if (st != UBDPT_SUCCESS) break;
-            ck(hipMalloc((void**)&b.d_pool_next, 2 * sizeof(uint32_t)));
+            ck(hipMalloc((void**)&b.d_pool_next, 4 * sizeof(uint32_t)));
             if (st != UBDPT_SUCCESS) break;
-            const uint32_t pool_pages = c->pages_per_k ? (uint32_t)std::max<uint64_t>(64, c->cap_paths * c->pages_per_k / 1024) : 0u;
+            ck(hipMemsetAsync(b.d_pool_next, 0, 4 * sizeof(uint32_t), c->stream));
+            // the pool: vertex_pool_pages per 1024 subpaths of a batch, and never less than 1024 subpaths can fill whatever
+            // happens (a batch that exhausts the pool is rendered again in pieces, which must end somewhere).
+            // UBDPT_POOL_PAGES sets the number itself, for tests of that path.
+            uint32_t pool_pages = c->pages_per_k ? (uint32_t)std::max<uint64_t>(1024ull * c->page_levels, c->cap_paths * c->pages_per_k / 1024) : 0u;
+            if (const char* e = getenv("UBDPT_POOL_PAGES")) { if (c->pages_per_k && atoi(e) > 0) pool_pages = std::max<uint32_t>((uint32_t)atoi(e), c->page_levels); }
+            c->pool_pages = pool_pages;
+            c->safe_paths = c->page_levels ? pool_pages / c->page_levels : c->cap_paths;
+            // what a batch adds to the sum buffers and to the counters is collected per lane and handed on when the batch
+            // is complete: one buffer, or one per pass of a batch when the context keeps passes apart
+            c->fb_lane_slots = c->pass_slots ? std::max<uint32_t>(1, c->passes_in_flight) : 1;
+            ck(hipMalloc((void**)&b.d_fb_lane, sizeof(double) * 3 * c->npix * c->fb_lane_slots));
+            ck(hipMalloc((void**)&b.d_counters, sizeof(unsigned long long) * kNumCounters * K_NUM));
+            ck(hipHostMalloc((void**)&b.h_result, sizeof(uint32_t) * 4 * ubdpt_context::kResultRing, hipHostMallocDefault));
+            if (st != UBDPT_SUCCESS) break;
+            ck(hipMemsetAsync(b.d_fb_lane, 0, sizeof(double) * 3 * c->npix * c->fb_lane_slots, c->stream));
+            ck(hipMemsetAsync(b.d_counters, 0, sizeof(unsigned long long) * kNumCounters * K_NUM, c->stream));
+            memset(b.h_result, 0, sizeof(uint32_t) * 4 * ubdpt_context::kResultRing);
             if ((st = allocStore(c, b.E, c->cap_paths, c->opt.max_path_vertices, c->dense_slots, pool_pages, b.d_pool_next)) != UBDPT_SUCCESS) break;
             if ((st = allocStore(c, b.L, c->cap_paths, c->opt.max_path_vertices, c->dense_slots, pool_pages, b.d_pool_next + 1)) != UBDPT_SUCCESS) break;
             uint64_t n2 = 2 * c->cap_paths;
@@ -682,6 +729,7 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         }
         }
         if (st != UBDPT_SUCCESS) break;
+        c->batch_limit = c->cap_paths;
         // set-up of the entry point that allocates nothing: this GPU's address of the static scratch array (asked for with
         // this GPU current) and a pinned word block its counters are copied to
         ck(noAllocScratch(device, &c->noalloc_scratch));
@@ -711,14 +759,6 @@ int ubdpt_destroy(ubdpt_context* c) {
 // A ray whose traversal stack was full dropped a subtree: whatever was computed with it may miss a hit.
 // The call that finds the counter set fails; the counter is cleared so that the context stays usable.
 static int reportStackOverflows(ubdpt_context* c) {
-    if (c->pool_overflows) {
-        fprintf(stderr, "ubdpt: %llu subpaths needed vertex slots beyond the first %u when the pool of pages for them was empty; the "
-                "result of this call is not valid (raise ubdpt_options.vertex_pool_pages, now %u per 1024 subpaths, or set "
-                "dense_vertex_slots = max_path_vertices)\n", (unsigned long long)c->pool_overflows, c->dense_slots, c->pages_per_k);
-        c->pool_overflows = 0;
-        c->stack_overflows = 0;
-        return UBDPT_ERROR;
-    }
     if (!c->stack_overflows) return UBDPT_SUCCESS;
     fprintf(stderr, "ubdpt: traversal stack overflow in %llu waves or rays; the result of this call is not valid\n",
             (unsigned long long)c->stack_overflows);
@@ -741,12 +781,181 @@ static int flushHeld(ubdpt_context* c) {
     return st;
 }
 
+
+// One batch: pixel-samples [d.pos, d.pos + d.n) of the call d.call, on the next lane.
+static int launchBatch(ubdpt_context* c, const ubdpt_context::BatchDesc& d, bool redo) {
+    const bool stats = c->opt.collect_stats != 0;
+    const bool separate = d.call.separate;
+    const uint64_t nbatch = d.n, pos = d.pos;
+    uint64_t& batch = c->next_batch;
+    ubdpt_context::BatchLane& B = c->lanes[batch % c->lanes.size()];
+    hipStream_t sm = B.stream;
+    RenderArgs A;
+    A.S = c->S;
+    A.E = B.E; A.L = B.L;
+    A.E.n = A.L.n = nbatch;
+    // the wavefront pipeline keeps the live count words inside the carry records (below); the stores' own dense
+    // arrays take the count words of the finished subpaths
+    A.fin_E = B.E.count; A.fin_L = B.L.count;
+    // what the batch adds goes to the lane's own sum buffers (one, or one per pass the batch touches when the call keeps
+    // its passes apart) and from there to the context's when the batch is complete
+    const uint64_t pass0 = pos / c->npix;
+    const uint32_t passes_touched = (uint32_t)((pos + nbatch - 1) / c->npix - pass0) + 1;
+    if (separate && passes_touched > c->fb_lane_slots) return UBDPT_ERROR;   // (batches are whole passes or parts of one)
+    A.fb = B.d_fb_lane;
+    A.fb_slots = separate ? passes_touched : 0;
+    A.first_pass = d.call.first_pass;
+    A.path_offset = pos;
+    A.batch_pass0 = pass0;
+    A.batch_pixel0 = pos % c->npix;
+    A.pass_stride = d.call.pass_stride;
+    A.seed = d.call.seed;
+    A.ovf = B.d_ovf; A.ovf_stride = A.E.n; A.ovf_cap = c->ovf_cap; A.pad_ovf = 0;
+    A.counters = B.d_counters;
+    A.batch_fail = B.d_pool_next + 2;
+    A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
+    A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
+    A.wf_hit = B.d_wf_hit; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
+    A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag; A.ray_pairs = B.d_ray_pairs;
+    double units = (double)A.E.n;
+    // grid-stride kernels: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers;
+    // 512 .. 16384 workgroups measured within 2 % of each other
+    unsigned pblocks = (unsigned)std::min<uint64_t>(kMaxGridLanes / 256, c->ovf_threads / 256);
+    // the two persistent ray tracing kernels: what the GPU holds at once (256 CUs x 4 workgroups of 4 waves). A
+    // larger grid only queues workgroups that find the ray queue empty; measured on the 2 M-triangle scene:
+    // 2048 workgroups 234, 1024: 239, 768: 231, 512: 225 Mpaths/s. UBDPT_TRACE_BLOCKS overrides it for measurements.
+    static const unsigned tblocks_env = [] { const char* e = getenv("UBDPT_TRACE_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
+    const unsigned tblocks = std::min(tblocks_env ? tblocks_env : 1024u, pblocks);
+    const uint64_t pstride = c->ovf_lanes;  // the wavefront kernels' grids have at most pblocks * 256 lanes
+    // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, setup, rays, compact, eval (default)
+    //           1 = per-path subpath kernels + per-path connection loop (the reference's loop structure, kept as a cross-check)
+    const uint32_t pl = c->opt.pipeline;
+    if (pl == 0) {
+        // the count word of subpath `id` is the eighth double of its carry record's first line (eye subpaths
+        // first, then the light subpaths), so trace and shade touch one line less per subpath
+        const uint32_t stride = kCarryDoubles * (uint32_t)(sizeof(double) / sizeof(uint32_t));
+        A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + kCarryCountSlot);
+        A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + kCarryCountSlot);
+        A.E.count_stride = A.L.count_stride = stride;
+    }
+    const uint32_t D = c->wf_depth;
+    auto run = [&](int kernel, double u, auto&& launch) {
+        A.counters = B.d_counters + kernel * kNumCounters;
+        c->beginTimedLane(B, kernel, u); launch(); c->endTimedLane(B);
+    };
+    HIPCK(c, hipMemsetAsync(B.d_pool_next, 0, 4 * sizeof(uint32_t), sm));
+    if (pl == 0) {
+        HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
+        A.ovf_stride = pstride;
+        run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
+        for (uint32_t dd = 0; dd < D; dd++) {
+            run(K_WF_TRACE, dd == 0 ? units : 0, [&] { launchWfTrace(A, dd, tblocks, pblocks, stats, sm); });
+            run(K_WF_SHADE, dd == 0 ? units : 0, [&] { launchWfShade(A, dd, pblocks, stats, sm); });
+        }
+        run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
+        HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
+        HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
+        HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 4 * sizeof(uint32_t), sm));
+        run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, pblocks, stats, sm); });
+        if (sceneLdsLevel(A.S) == 2) {
+            run(K_RAYS_VISIBLE, units, [&] { launchPairVisibleLds(A, pblocks, stats, sm); });
+        } else {
+            run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
+            run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, tblocks, stats, sm); });
+            run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
+        }
+        run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
+    } else {
+        A.ovf_stride = A.E.n;
+        run(K_EYE, units, [&] { launchEye(A, stats, sm); });
+        run(K_LIGHT, units, [&] { launchLight(A, stats, sm); });
+        run(K_CONNECT, units, [&] { launchConnect(A, stats, sm); });
+    }
+    // the batch's sums and counters move on to the context's (or are dropped, when the batch could not be completed), and
+    // the host is told which of the two it was
+    double* target = c->d_fb + (separate ? 3 * c->npix * (1 + (uint64_t)d.call.first_slot + pass0) : 0);
+    launchCommitBatch(B.d_fb_lane, c->npix, separate ? passes_touched : 1, target, B.d_pool_next + 2, B.d_counters, c->d_counters,
+                      (uint32_t)(kNumCounters * K_NUM), sm);
+    uint32_t* result = B.h_result + 4 * (B.seq++ % ubdpt_context::kResultRing);
+    HIPCK(c, hipMemcpyAsync(result, B.d_pool_next, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, sm));
+    HIPCK(c, hipGetLastError());
+    batch++;
+    // keep at most a few batches (about 16 M pixel-samples) queued per lane, so that a stop request is
+    // honoured promptly and the host does not run arbitrarily far ahead of the device
+    // (the pieces of a batch that is rendered again were counted as progress when the batch was enqueued)
+    c->markBatch(B, redo ? 0 : nbatch, d, result);
+    const size_t max_inflight = (size_t)std::max<uint64_t>(2, std::min<uint64_t>(64, (16ull << 20) / std::max<uint64_t>(1, c->cap_paths)));
+    HIPCK(c, c->throttle(B, max_inflight));
+    return UBDPT_SUCCESS;
+}
+
+// Batches for the pixel-samples [pos, end) of a call, `pos` moving along. From pixel-sample `stop_from` on a stop request
+// ends the range at the next pass boundary (UBDPT_STOPPED). Batches that failed meanwhile are rendered again on the way.
+static int processRedo(ubdpt_context* c);
+static int enqueueRange(ubdpt_context* c, const ubdpt_context::CallDesc& call, uint64_t& pos, uint64_t end, uint64_t stop_from,
+                        bool redo = false) {
+    while (pos < end) {
+        if (!redo && pos % c->npix == 0 && pos >= stop_from && c->stop.load()) return UBDPT_STOPPED;
+        // whole passes, or a range of pixels inside one pass (never across a pass boundary)
+        uint64_t lim = std::min(c->cap_paths, c->batch_limit);
+        if (lim >= c->npix) lim = lim / c->npix * c->npix;
+        uint64_t nbatch = std::min<uint64_t>(lim, end - pos);
+        if (lim < c->npix) nbatch = std::min<uint64_t>(nbatch, c->npix - pos % c->npix);
+        ubdpt_context::BatchDesc d;
+        d.call = call; d.pos = pos; d.n = nbatch;
+        int st = launchBatch(c, d, redo);
+        if (st != UBDPT_SUCCESS) return st;
+        pos += nbatch;
+        if (!redo && !c->redo.empty()) {
+            st = processRedo(c);
+            if (st != UBDPT_SUCCESS) return st;
+        }
+    }
+    return UBDPT_SUCCESS;
+}
+
+// Renders the batches again that could not be completed, in pieces the pool of deep vertex slots can serve: the pages
+// a failed batch asked for (a lower bound of what it needs: a subpath that was turned away asks for nothing more) say
+// into how many pieces to cut it; a piece of safe_paths pixel-samples cannot fail. The batches that follow are made as
+// small as the pieces: the scene is what exhausts the pool, and it stays.
+static int processRedo(ubdpt_context* c) {
+    while (!c->redo.empty()) {
+        const ubdpt_context::Failed f = c->redo.back();
+        c->redo.pop_back();
+        if (f.desc.n <= c->safe_paths || c->pool_pages == 0) {
+            fprintf(stderr, "ubdpt: a batch of %llu pixel-samples exhausted a pool of %u pages (internal error)\n",
+                    (unsigned long long)f.desc.n, c->pool_pages);
+            return UBDPT_ERROR;
+        }
+        const uint64_t asked = std::max(f.asked_eye, f.asked_light);
+        const uint64_t pieces = std::max<uint64_t>(2, (3 * asked / 2 + c->pool_pages - 1) / c->pool_pages);
+        uint64_t lim = std::max<uint64_t>(c->safe_paths, f.desc.n / pieces);
+        if (lim >= c->npix) lim = lim / c->npix * c->npix;
+        c->batch_limit = std::min(c->batch_limit, lim);
+        c->batches_redone++;
+        uint64_t pos = f.desc.pos;
+        int st = enqueueRange(c, f.desc.call, pos, f.desc.pos + f.desc.n, UINT64_MAX, true);
+        if (st != UBDPT_SUCCESS) return st;
+    }
+    return UBDPT_SUCCESS;
+}
+
+// Waits for everything that was enqueued, batches that have to be rendered again included.
+static int settle(ubdpt_context* c) {
+    for (;;) {
+        for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
+        c->collectLanes();
+        if (c->redo.empty()) return UBDPT_SUCCESS;
+        int st = processRedo(c);
+        if (st != UBDPT_SUCCESS) return st;
+    }
+}
+
 static int finishPending(ubdpt_context* c) {
     if (!c->work_pending) return UBDPT_SUCCESS;
     { int fh = flushHeld(c); if (fh != UBDPT_SUCCESS) return fh; }
-    for (auto& b : c->lanes) HIPCK(c, hipStreamSynchronize(b.stream));
+    { int ss = settle(c); if (ss != UBDPT_SUCCESS) return ss; }
     c->work_pending = false;
-    c->collectLanes();
     c->collectTimed();
     int fc = fetchCounters(c);
     if (fc != UBDPT_SUCCESS) return fc;
@@ -796,18 +1005,20 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
             int f = c->slot_fence[s];
             if (f < 0 || seen[f]) continue;
             seen[f] = true;
-            for (hipEvent_t ev : c->fences[f]) HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0));
+            // (waited for on the host as well: one of those batches may have to be rendered again, see processRedo, and
+            // that must not happen after the clear. When the buffers were read, their batches finished long ago)
+            for (hipEvent_t ev : c->fences[f]) { HIPCK(c, hipEventSynchronize(ev)); HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0)); }
         }
+        c->reapFinished();
+        if (!c->redo.empty()) { int ss = settle(c); if (ss != UBDPT_SUCCESS) return ss; }
         HIPCK(c, hipMemsetAsync(c->d_fb + 3 * c->npix * (1 + (uint64_t)first_slot), 0, sizeof(double) * 3 * c->npix * n_passes, c->stream));
         if (!c->clear_ev) HIPCK(c, hipEventCreateWithFlags(&c->clear_ev, hipEventDisableTiming));
         HIPCK(c, hipEventRecord(c->clear_ev, c->stream));
         for (auto& b : c->lanes) HIPCK(c, hipStreamWaitEvent(b.stream, c->clear_ev, 0));
     }
     if (!c->work_pending) { c->work_pending = true; c->pending_since = nowSeconds(); }
-    bool stats = c->opt.collect_stats != 0;
     uint32_t done = 0;
     int status = UBDPT_SUCCESS;
-    uint64_t& batch = c->next_batch;
     // pixel-samples of this call in (pass, pixel) order; a batch is a contiguous range of them: whole passes, or
     // (when the batch size is below one pass) a range of pixels inside one pass
     // a call that is not waited for leaves the passes that do not fill a batch to the next call (see Held), provided
@@ -816,99 +1027,15 @@ static int renderPassesLocked(ubdpt_context* c, uint64_t first_pass, uint32_t n_
     if (may_hold && !wait && !separate && c->cap_paths >= c->npix && c->passes_in_flight > 1 && n_passes > c->passes_in_flight)
         hold = n_passes % c->passes_in_flight;
     const uint64_t total_paths = (uint64_t)(n_passes - hold) * c->npix;
+    ubdpt_context::CallDesc call;
+    call.first_pass = first_pass; call.pass_stride = pass_stride; call.seed = seed; call.separate = separate; call.first_slot = first_slot;
     uint64_t pos = 0;
-    while (pos < total_paths) {
-        // (the passes taken over from an earlier call were promised by that call: a stop request does not drop them)
-        if (pos % c->npix == 0 && pos >= (uint64_t)merged * c->npix && !c->flushing_held && c->stop.load()) { status = UBDPT_STOPPED; break; }
-        uint64_t nbatch = std::min<uint64_t>(c->cap_paths, total_paths - pos);
-        if (c->cap_paths < c->npix) nbatch = std::min<uint64_t>(nbatch, c->npix - pos % c->npix);
-        ubdpt_context::BatchLane& B = c->lanes[batch % c->lanes.size()];
-        hipStream_t sm = B.stream;
-        RenderArgs A;
-        A.S = c->S;
-        A.E = B.E; A.L = B.L;
-        A.E.n = A.L.n = nbatch;
-        // the wavefront pipeline keeps the live count words inside the carry records (below); the stores' own dense
-        // arrays take the count words of the finished subpaths
-        A.fin_E = B.E.count; A.fin_L = B.L.count;
-        // per-pass buffers: pass j of the call adds into buffer 1 + first_slot + j (the kernels see the sum buffers
-        // shifted by first_slot buffers and take j modulo the buffers that remain, which is j)
-        A.fb = c->d_fb + (separate ? 3 * c->npix * (uint64_t)first_slot : 0);
-        A.fb_slots = separate ? c->pass_slots - first_slot : 0;
-        A.first_pass = first_pass;
-        A.path_offset = pos;
-        A.batch_pass0 = pos / c->npix;
-        A.batch_pixel0 = pos % c->npix;
-        A.pass_stride = pass_stride;
-        A.seed = seed;
-        A.ovf = B.d_ovf; A.ovf_stride = A.E.n; A.ovf_cap = c->ovf_cap; A.pad_ovf = 0;
-        A.counters = c->d_counters;
-        A.pairs = B.d_pairs; A.pair_capacity = c->pair_capacity; A.pair_count = B.d_pair_count;
-        A.carry = B.d_carry; A.wf_trace_q = B.d_wf_trace_q; A.wf_count = B.d_wf_count;
-        A.wf_hit = B.d_wf_hit; A.vis_pairs = B.d_vis_pairs; A.vis_count = B.d_vis_count;
-        A.rays = B.d_rays; A.ray_count = B.d_ray_count; A.ray_head = B.d_ray_count + 1; A.ray_flag = B.d_ray_flag; A.ray_pairs = B.d_ray_pairs;
-        double units = (double)A.E.n;
-        // grid-stride kernels: at most 2048 workgroups (8 per CU), never more lanes than the stack overflow buffer covers;
-        // 512 .. 16384 workgroups measured within 2 % of each other
-        unsigned pblocks = (unsigned)std::min<uint64_t>(kMaxGridLanes / 256, c->ovf_threads / 256);
-        // the two persistent ray tracing kernels: what the GPU holds at once (256 CUs x 4 workgroups of 4 waves). A
-        // larger grid only queues workgroups that find the ray queue empty; measured on the 2 M-triangle scene:
-        // 2048 workgroups 234, 1024: 239, 768: 231, 512: 225 Mpaths/s. UBDPT_TRACE_BLOCKS overrides it for measurements.
-        static const unsigned tblocks_env = [] { const char* e = getenv("UBDPT_TRACE_BLOCKS"); return e ? (unsigned)atoi(e) : 0u; }();
-        const unsigned tblocks = std::min(tblocks_env ? tblocks_env : 1024u, pblocks);
-        const uint64_t pstride = c->ovf_lanes;  // the wavefront kernels' grids have at most pblocks * 256 lanes
-        // pipeline: 0 = wavefront, small kernels: gen, D x (trace, shade), tail; pair enum, setup, rays, compact, eval (default)
-        //           1 = per-path subpath kernels + per-path connection loop (the reference's loop structure, kept as a cross-check)
-        const uint32_t pl = c->opt.pipeline;
-        if (pl == 0) {
-            // the count word of subpath `id` is the eighth double of its carry record's first line (eye subpaths
-            // first, then the light subpaths), so trace and shade touch one line less per subpath
-            const uint32_t stride = kCarryDoubles * (uint32_t)(sizeof(double) / sizeof(uint32_t));
-            A.E.count = reinterpret_cast<uint32_t*>(B.d_carry + kCarryCountSlot);
-            A.L.count = reinterpret_cast<uint32_t*>(B.d_carry + A.E.n * kCarryDoubles + kCarryCountSlot);
-            A.E.count_stride = A.L.count_stride = stride;
-        }
-        const uint32_t D = c->wf_depth;
-        auto run = [&](int kernel, double u, auto&& launch) {
-            A.counters = c->d_counters + kernel * kNumCounters;
-            c->beginTimedLane(B, kernel, u); launch(); c->endTimedLane(B);
-        };
-        HIPCK(c, hipMemsetAsync(B.d_pool_next, 0, 2 * sizeof(uint32_t), sm));
-        if (pl == 0) {
-            HIPCK(c, hipMemsetAsync(B.d_wf_count, 0, sizeof(uint32_t) * kWfQStride * (D + 2), sm));
-            A.ovf_stride = pstride;
-            run(K_WF_GEN, 2 * units, [&] { launchWfGen(A, stats, sm); });
-            for (uint32_t d = 0; d < D; d++) {
-                run(K_WF_TRACE, d == 0 ? units : 0, [&] { launchWfTrace(A, d, tblocks, pblocks, stats, sm); });
-                run(K_WF_SHADE, d == 0 ? units : 0, [&] { launchWfShade(A, d, pblocks, stats, sm); });
-            }
-            run(K_WF_TAIL, units, [&] { launchWfTail(A, D, pblocks, stats, sm); });
-            HIPCK(c, hipMemsetAsync(B.d_pair_count, 0, sizeof(unsigned long long), sm));
-            HIPCK(c, hipMemsetAsync(B.d_vis_count, 0, sizeof(uint32_t), sm));
-            HIPCK(c, hipMemsetAsync(B.d_ray_count, 0, 4 * sizeof(uint32_t), sm));
-            run(K_PAIR_ENUM, units, [&] { launchPairEnum(A, pblocks, stats, sm); });
-            if (sceneLdsLevel(A.S) == 2) {
-                run(K_RAYS_VISIBLE, units, [&] { launchPairVisibleLds(A, pblocks, stats, sm); });
-            } else {
-                run(K_PAIR_SETUP, units, [&] { launchPairSetup(A, pblocks, stats, sm); });
-                run(K_RAYS_VISIBLE, units, [&] { launchRaysVisible(A, tblocks, stats, sm); });
-                run(K_PAIR_COMPACT, units, [&] { launchPairCompact(A, pblocks, sm); });
-            }
-            run(K_PAIR_EVAL, units, [&] { launchPairEval(A, pblocks, stats, sm); });
-        } else {
-            A.ovf_stride = A.E.n;
-            run(K_EYE, units, [&] { launchEye(A, stats, sm); });
-            run(K_LIGHT, units, [&] { launchLight(A, stats, sm); });
-            run(K_CONNECT, units, [&] { launchConnect(A, stats, sm); });
-        }
-        HIPCK(c, hipGetLastError());
-        pos += nbatch;
-        batch++;
-        // keep at most a few batches (about 16 M pixel-samples) queued per lane, so that a stop request is
-        // honoured promptly and the host does not run arbitrarily far ahead of the device
-        c->markBatch(B, nbatch);
-        const size_t max_inflight = (size_t)std::max<uint64_t>(2, std::min<uint64_t>(64, (16ull << 20) / std::max<uint64_t>(1, c->cap_paths)));
-        HIPCK(c, c->throttle(B, max_inflight));
+    // (the passes taken over from an earlier call were promised by that call: a stop request does not drop them)
+    const uint64_t stop_from = c->flushing_held ? UINT64_MAX : (uint64_t)merged * c->npix;
+    {
+        int es = enqueueRange(c, call, pos, total_paths, stop_from);
+        if (es == UBDPT_STOPPED) status = es;
+        else if (es != UBDPT_SUCCESS) return es;
     }
     done = (uint32_t)(pos / c->npix);
     c->stats.passes += done;
@@ -1051,8 +1178,11 @@ static int readSumBuffer(ubdpt_context* c, uint32_t buffer, const double* base, 
     HIPCK(c, hipSetDevice(c->device));
     const int fence = (buffer >= 1 && c->work_pending) ? c->slot_fence[buffer - 1] : -1;
     if (fence >= 0) {
-        // filled by ubdpt_enqueue_passes_separate: the copy stream waits for the batches of that call only
-        for (hipEvent_t ev : c->fences[fence]) HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0));
+        // filled by ubdpt_enqueue_passes_separate: waits for the batches of that call only; should one of them have to
+        // be rendered again, for that too
+        for (hipEvent_t ev : c->fences[fence]) { HIPCK(c, hipEventSynchronize(ev)); HIPCK(c, hipStreamWaitEvent(c->stream, ev, 0)); }
+        c->reapFinished();
+        if (!c->redo.empty()) { int ss = settle(c); if (ss != UBDPT_SUCCESS) return ss; }
     } else {
         int fs_ = finishPending(c);
         if (fs_ != UBDPT_SUCCESS) return fs_;
@@ -1326,6 +1456,15 @@ int ubdpt_get_batch_info(ubdpt_context* c, uint64_t* pixel_samples_per_batch, ui
     if (pixel_samples_per_batch) *pixel_samples_per_batch = c->cap_paths;
     if (lanes) *lanes = (uint32_t)c->lanes.size();
     if (wavefront_depth) *wavefront_depth = c->wf_depth;
+    return UBDPT_SUCCESS;
+}
+
+int ubdpt_get_recovery_info(ubdpt_context* c, uint64_t* batches_rendered_again, uint64_t* pixel_samples_per_batch_now) {
+    if (!c) return UBDPT_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->work_pending) { hipSetDevice(c->device); int fs_ = finishPending(c); if (fs_ != UBDPT_SUCCESS) return fs_; }
+    if (batches_rendered_again) *batches_rendered_again = c->batches_redone;
+    if (pixel_samples_per_batch_now) *pixel_samples_per_batch_now = std::min(c->cap_paths, c->batch_limit);
     return UBDPT_SUCCESS;
 }
 

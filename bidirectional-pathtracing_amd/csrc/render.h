@@ -11,10 +11,12 @@ namespace ub {
 struct RenderArgs {
     DScene S;
     PathStore E, L;        // eye / light subpath vertices of the batch
-    double* fb;            // planar sum buffer: R[npix], G[npix], B[npix]
+    double* fb;            // planar sum buffers of the batch lane (R[npix], G[npix], B[npix] each): what the batch adds is
+                           // collected here and handed on to the context's buffers by k_commit_batch when the batch is complete
     uint64_t first_pass, pass_stride, seed;
     uint64_t path_offset;  // index of the batch's first pixel-sample among the call's n_passes * npix
-    uint64_t fb_slots;     // > 0: the pass with index j among the call's passes adds into per-pass sum buffer j % fb_slots (they follow fb)
+    uint64_t fb_slots;     // 0: everything adds into the first buffer at fb; > 0: the passes are kept apart, the q-th pass the
+                           // batch touches adds into buffer q
     uint64_t batch_pass0;  // path_offset / npix and path_offset % npix, split on the host: the kernels then divide
     uint64_t batch_pixel0; // (batch_pixel0 + i), a number that almost always fits 32 bits, instead of a 64-bit index
     int32_t* ovf;          // traversal-stack overflow, [kOverflowStack][ovf_stride]
@@ -22,6 +24,7 @@ struct RenderArgs {
     uint32_t ovf_cap;      // entries of a lane's whole stack, on-chip part included (ubdpt_options.traversal_stack_entries)
     uint32_t pad_ovf;
     unsigned long long* counters;
+    uint32_t* batch_fail;  // set when the batch cannot be completed (the pool of deep vertex slots ran empty): its sums are dropped
     uint64_t* pairs;                  // connection queue: (path << 16) | (s << 8) | t
     unsigned long long pair_capacity;
     unsigned long long* pair_count;   // device counter, zeroed before every batch
@@ -88,6 +91,11 @@ void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_r
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchInterleaveAdd(const double* fb, uint64_t npix, double* out, hipStream_t s);
 void launchDeinterleave(const double* in, uint64_t npix, double* fb, hipStream_t s);
+// End of a batch: the lane's `slots` sum buffers (3 * npix doubles each) are added to the buffers from `target` on and
+// cleared, its counter words are added to `counters` and cleared; when *fail is set the sums and the counters are dropped
+// (all but C_POOL_OVERFLOW), and the host renders the batch again in smaller pieces.
+void launchCommitBatch(double* lane_fb, uint64_t npix, uint32_t slots, double* target, const uint32_t* fail,
+                       unsigned long long* lane_counters, unsigned long long* counters, uint32_t counter_words, hipStream_t s);
 // sums of the CIE 1931 fits over the three 123 nm bins (uengine/uconverter.cpp:31-76), computed once on the host
 struct RgbFit { d3 sumX, sumY, sumZ; };
 void launchImageRgb(const double* fb, uint64_t npix, double passes, double gamma, const RgbFit& fit, double* out,

@@ -89,14 +89,20 @@ DEV void decodePassPixel(const RenderArgs& A, uint64_t gid, uint64_t& pass_index
     pass_index = A.batch_pass0 + q;
 }
 
-// With fb_slots > 0 the passes of a call are kept apart: the pass with index j among the call's passes adds into
-// per-pass sum buffer j % fb_slots; these follow the sum buffer proper, 3 * npix doubles each. Returns the offset
-// for the pixel-sample gid of the batch; it is added to the pixel index handed to fbAdd.
+// With fb_slots > 0 the passes of a call are kept apart: the q-th pass the batch touches adds into the lane's sum buffer
+// q (3 * npix doubles each). Returns the offset for the pixel-sample gid of the batch; it is added to the pixel index
+// handed to fbAdd.
 DEV uint64_t fbSlotOffset(const RenderArgs& A, uint64_t gid) {
     if (A.fb_slots == 0) return 0;
     uint64_t pass_index, pixel;
     decodePassPixel(A, gid, pass_index, pixel);
-    return (1 + pass_index % A.fb_slots) * 3ull * ((uint64_t)A.S.img_res_x * A.S.img_res_y);
+    return (pass_index - A.batch_pass0) * 3ull * ((uint64_t)A.S.img_res_x * A.S.img_res_y);
+}
+
+// A subpath found the pool of deep vertex slots empty and ends here: the batch cannot be completed as it is.
+DEV void poolExhausted(const RenderArgs& A) {
+    atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL);
+    *A.batch_fail = 1u;
 }
 
 DEV void decodePath(const RenderArgs& A, uint64_t gid, uint64_t& pass, uint64_t& pixel, uint32_t& px, uint32_t& py) {
@@ -202,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_eye(RenderArgs A) {
             break;
         finishVertex(obj, nv, dirT);
         I = I + s0sample(S, E, gid, n, cur, prev_specular, nv);
-        if (!E.openSlot(n, gid)) { atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL); break; }
+        if (!E.openSlot(n, gid)) { poolExhausted(A); break; }
         storeVertex(E, n, gid, nv);
         smask |= specularBit(n, nv.specular);
         n++;
@@ -377,7 +383,7 @@ __global__ __launch_bounds__(kBlock) void k_light(RenderArgs A) {
                              rng(hitDim(h, DIM_SCATTER_2)), dT, p_psa, fs, nv.specular))
                 break;
             finishVertex(obj, nv, dT);
-            if (!L.openSlot(n, gid)) { atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL); break; }
+            if (!L.openSlot(n, gid)) { poolExhausted(A); break; }
             storeVertex(L, n, gid, nv);
             smask |= specularBit(n, nv.specular);
             n++;
@@ -880,6 +886,31 @@ __global__ void k_interleave_add(const double* fb, uint64_t npix, double* out) {
     out[3 * i + 1] += fb[npix + i];
     out[3 * i + 2] += fb[2 * npix + i];
 }
+// End of a batch (see launchCommitBatch in render.h). The other lane's batches may be committing into the same buffers:
+// atomic adds. Most values of a lane's buffers are non-zero after a batch; the zeros are skipped all the same.
+__global__ __launch_bounds__(kBlock) void k_commit_batch(double* lane_fb, uint64_t n, double* target, const uint32_t* fail,
+                                                         unsigned long long* lane_counters, unsigned long long* counters,
+                                                         uint32_t counter_words) {
+    const bool failed = *fail != 0;
+    const uint64_t gid = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+    if (gid < counter_words) {
+        const unsigned long long v = lane_counters[gid];
+        if (v) {
+            lane_counters[gid] = 0;
+            const uint32_t which = (uint32_t)gid % kNumCounters;
+            if (which == C_MAX_STACK) { if (!failed) atomicMax(&counters[gid], v); }
+            else if (!failed || which == C_POOL_OVERFLOW) atomicAdd(&counters[gid], v);
+        }
+    }
+    for (uint64_t i = gid; i < n; i += stride) {
+        const double v = lane_fb[i];
+        if (v != 0) {   // (true for NaN as well)
+            lane_fb[i] = 0;
+            if (!failed) unsafeAtomicAdd(target + i, v);
+        }
+    }
+}
 __global__ void k_deinterleave(const double* in, uint64_t npix, double* fb) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
@@ -1041,6 +1072,12 @@ void launchBsdfBatch(int mode, const ubdpt_bsdf_query* q, size_t n, ubdpt_bsdf_r
 }
 void launchInterleave(const double* fb, uint64_t npix, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_interleave, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, out);
+}
+void launchCommitBatch(double* lane_fb, uint64_t npix, uint32_t slots, double* target, const uint32_t* fail,
+                       unsigned long long* lane_counters, unsigned long long* counters, uint32_t counter_words, hipStream_t s) {
+    const uint64_t n = 3ull * npix * slots;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(2048, std::max<uint64_t>((n + kBlock - 1) / kBlock, (counter_words + kBlock - 1) / kBlock));
+    hipLaunchKernelGGL(k_commit_batch, dim3(blocks), dim3(kBlock), 0, s, lane_fb, n, target, fail, lane_counters, counters, counter_words);
 }
 void launchInterleaveAdd(const double* fb, uint64_t npix, double* out, hipStream_t s) {
     hipLaunchKernelGGL(k_interleave_add, dim3(gridFor(npix)), dim3(kBlock), 0, s, fb, npix, out);

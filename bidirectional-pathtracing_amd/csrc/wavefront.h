@@ -179,7 +179,7 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
         d3 I = s0sample(S, P, i, n, cur, prev_specular, nv);
         if (I.x != 0 || I.y != 0 || I.z != 0) { fbAdd(A.fb, npix, pixel + fbSlotOffset(A, i), I); if (STATS) ty.fb++; }
     }
-    if (!P.openSlot(n, i)) { atomicAdd(&A.counters[C_POOL_OVERFLOW], 1ULL); return false; }
+    if (!P.openSlot(n, i)) { poolExhausted(A); return false; }
     storeVertex(P, n, i, nv);
     n++;
     meta = ((meta & 0xffffff00u) | specularBit(n - 1, nv.specular)) | n;

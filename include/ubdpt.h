@@ -138,9 +138,11 @@ typedef struct ubdpt_options {
                                    pool, to the few subpaths that get that far (1 in 10 000 reaches slot 16 on box scenes
                                    with glass): a third less memory per pixel-sample, larger batches. */
     uint32_t vertex_pool_pages;  /* size of that pool: pages per 1024 subpaths of a batch; 0 -> 128 (one subpath in eight
-                                   can hold a page). A batch that needs more makes the call that rendered it return
-                                   UBDPT_ERROR (a truncated subpath is never handed out silently): raise this, or store
-                                   every slot densely (dense_vertex_slots = max_path_vertices). */
+                                   can hold a page). A batch that needs more is not handed out: its sums are dropped on the
+                                   device, it is rendered again in pieces the pool can serve (same samples, same image), and
+                                   the batches after it are made that small (ubdpt_get_recovery_info tells). A scene that
+                                   does this often (a closed room of mirrors) runs faster with a larger pool or with every
+                                   slot stored densely (dense_vertex_slots = max_path_vertices). */
 } ubdpt_options;
 
 /* ---- batch intersection (parity probe for UScene::intersectionPoint / visibility) ---- */
@@ -344,6 +346,12 @@ int ubdpt_get_image_size(ubdpt_context* ctx, uint64_t* width, uint64_t* height);
  * run as wavefront launches before the tail loop. What ubdpt_create settled on after sizing the batches to the memory
  * that was free; the measurement tools relate per-launch counters to pixel-samples with it. Any pointer may be NULL. */
 int ubdpt_get_batch_info(ubdpt_context* ctx, uint64_t* pixel_samples_per_batch, uint32_t* lanes, uint32_t* wavefront_depth);
+
+/* Batches that exhausted the pool of deep vertex slots (ubdpt_options.vertex_pool_pages) and were rendered again in
+ * smaller pieces, since the context was created, and the pixel-samples a batch holds now (lowered whenever that happened).
+ * No counterpart in the reference, whose subpaths are std::vectors that grow (uengine/ubdptrenderer.cpp:224-229).
+ * Waits for the enqueued passes. Any pointer may be NULL. */
+int ubdpt_get_recovery_info(ubdpt_context* ctx, uint64_t* batches_rendered_again, uint64_t* pixel_samples_per_batch_now);
 
 int ubdpt_get_stats(ubdpt_context* ctx, ubdpt_stats* out);
 int ubdpt_reset_stats(ubdpt_context* ctx);
