@@ -211,31 +211,58 @@ DEV bool shadeStep(const RenderArgs& A, uint64_t i, uint64_t pixel, const Rng& r
     return true;
 }
 
+// Records of consecutive subpaths lie side by side in memory. A lane that writes its own record with 16-byte stores
+// makes every store instruction touch 64 different lines; measured on this part a kernel that only stores 192-byte
+// records gets 3.7 TB/s that way, 5.6 TB/s when the wave stages the records in LDS and writes them out so that
+// consecutive lanes store consecutive 16-byte pieces, 6.9 TB/s for a plain streaming store (tools/store_bench.hip).
+// waveStore: every lane of the wave hands in PIECES pieces of its record; the record of lane l starts at
+// dst0 + l * stride_doubles + 2 * first_piece doubles. All 64 lanes must take part.
+constexpr int kStagePieces = 4;
+template <int PIECES>
+DEV void waveStore(v2d* stage, int lane, const v2d (&piece)[PIECES], double* dst0, uint32_t stride_doubles, int first_piece) {
+    static_assert(PIECES <= kStagePieces, "stage too small");
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) stage[lane * PIECES + k] = piece[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const int p = k * 64 + lane;
+        const int r = p / PIECES, q = p - r * PIECES;
+        *reinterpret_cast<v2d*>(dst0 + (uint64_t)r * stride_doubles + 2 * (first_piece + q)) = stage[p];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+DEV v2d mk2(double a, double b) { v2d v; v.x = a; v.y = b; return v; }
+
 // ---- generation ---------------------------------------------------------------------------------------
 // Vertex 0 and the first ray of every subpath (eye: lens vertex and primary ray, :231-257; light: emitter vertex and
 // emission ray, :413-454): stores the vertex, the count word and the carry record.
 template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
+    __shared__ v2d s_stage[kBlock / 64][64 * kStagePieces];
     uint64_t id = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
     const DScene& S = A.S;
     uint64_t N = A.E.n;
+    const int lane = threadIdx.x & 63;
+    v2d* stage = s_stage[threadIdx.x >> 6];
     bool live = false;
+    const bool light = id >= N;
+    const uint64_t i = light ? id - N : id;
+    Carry cy;
+    cy.pos = cy.dir = cy.a = cy.Ns = mk3(0, 0, 0);
+    cy.p_psa = 0; cy.q = 1.0; cy.pending = 0;
+    Vertex v0;   // lens or emitter vertex
     if (id < 2 * N) {
-        bool light = id >= N;
-        uint64_t i = light ? id - N : id;
         uint64_t pass, pixel;
         uint32_t px, py;
         decodePath(A, i, pass, pixel, px, py);
         Rng rng{pathKey(A.seed, pass, pixel), light ? (uint32_t)STREAM_LIGHT : (uint32_t)STREAM_EYE};
-        Carry cy;
-        cy.pos = cy.dir = cy.a = cy.Ns = mk3(0, 0, 0);
-        cy.p_psa = 0; cy.q = 1.0; cy.pending = 0;
         if (!light) {
             uint32_t pixel_sample = (uint32_t)(pass % S.num_pixel_strata);
             uint32_t lens_sample = (uint32_t)(pass % S.num_lens_strata);
             d2 disk = sampleUnitDiskStratified(S.num_lens_strata, lens_sample, rng(DIM_LENS_X), rng(DIM_LENS_Y));
             d3 lens_pointV = mk3(S.lens_radius * disk.x, S.lens_radius * disk.y, 0);
-            Vertex lens;
+            Vertex& lens = v0;
             lens.a = mk3(1.0, 1.0, 1.0);
             lens.tex = mk3(0, 0, 0);
             lens.sp.pos = mul_xyz(S.invV, lens_pointV, 1.0);
@@ -246,8 +273,6 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             lens.p_eye_A = 1.0 / S.lens_area;  // lens_area is 0 in the reference -> +inf
             lens.p_light_A = 0;
             lens.specular = false;
-            storeLensVertex(A.E, i, lens);
-            A.E.setMeta(i, 1);
             d2 pp = sampleUnitRectStratified(S.num_pixel_strata, pixel_sample, rng(DIM_PIXEL_X), rng(DIM_PIXEL_Y));
             d3 image_pointV = mk3(-S.image_plane_ratio + ((double)px + pp.x) * S.pixel_width,
                                   1.0 - ((double)py + pp.y) * S.pixel_height, S.image_plane_distance);
@@ -267,7 +292,7 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             }
             if (ei < 0) ei = S.emitters[S.num_emitters - 1];
             const DObject& em = S.objects[ei];
-            Vertex ev;
+            Vertex& ev = v0;
             emitterRandomPoint(S, em, rng, ev.sp.pos, ev.sp.Ng, ev.sp.Ns, ev.sp.Ts, ev.sp.Bs);
             ev.sp.tex_u = 0; ev.sp.tex_v = 0; ev.sp.object = ei; ev.sp.lobe = LOBE_NONE; ev.sp.face = 0;
             ev.a = em.power;
@@ -275,20 +300,65 @@ __global__ __launch_bounds__(kBlock) void k_wf_gen(RenderArgs A) {
             ev.p_light_A = em.prob * (1.0 / em.area);
             ev.p_eye_A = 0;
             ev.specular = false;
-            storeVertex(A.L, 0, i, ev);
-            A.L.setMeta(i, 1);
             d3 dirT = samplePosHemUniform(rng(DIM_EMIT_ANGLE), rng(DIM_EMIT_V));
             cy.dir = float_tnb_mul(ev.sp.Ts, ev.sp.Ns, ev.sp.Bs, dirT);
             cy.p_psa = dirT.y;
             cy.pos = ev.sp.pos; cy.Ns = ev.sp.Ns; cy.a = ev.a;
             live = true;
-        } else {
-            A.L.setMeta(i, 0);
         }
-        if (live) {
-            if (light) storeCarry(A, id, cy);
-            else storeCarryRay(A, id, cy);  // the rest of an eye subpath's first record is constant, see loadCarry
+    }
+    // Stores: vertex 0, the count word and the carry record. A wave whose 64 lanes are all live subpaths of one kind (all
+    // but the wave at the border between the eye and the light subpaths and the last one) writes them together (waveStore),
+    // when the count words live inside the carry records (their eighth double), as they do in this pipeline.
+    const PathStore& P = light ? A.L : A.E;
+    const bool count_in_carry = reinterpret_cast<const double*>(P.count) == A.carry + (light ? N * kCarryDoubles : 0) + kCarryCountSlot &&
+                                P.count_stride == kCarryDoubles * 2;
+    const bool together = __all(live && count_in_carry) && __all(light) == __any(light);
+    if (together) {
+        const uint64_t i0 = i - (uint64_t)lane;
+        double of;
+        {
+            int32_t w[2] = {v0.sp.object, ((v0.sp.lobe + 1) & 0xff)};
+            __builtin_memcpy(&of, w, 8);
         }
+        const double meta1 = __longlong_as_double(1LL);   // count word 1 (one vertex, not specular) in the low half
+        double* vrec = P.rp(0, i0);
+        double* crec = A.carry + (id - (uint64_t)lane) * kCarryDoubles;
+        {   // line 0 of the vertex record, as storeVertex / storeLensVertex lay it out
+            v2d pc[4] = {mk2(v0.sp.pos.x, v0.sp.pos.y), mk2(v0.sp.pos.z, v0.p_light_A), mk2(v0.p_eye_A, of), mk2(0.0, 0.0)};
+            waveStore<4>(stage, lane, pc, vrec, kVertexDoubles, 0);
+        }
+        if (light) {
+            {
+                v2d pc[4] = {mk2(v0.tex.z, v0.sp.Ng.x), mk2(v0.sp.Ng.y, v0.sp.Ng.z), mk2(v0.sp.Ns.x, v0.sp.Ns.y), mk2(v0.sp.Ns.z, v0.sp.Ts.x)};
+                waveStore<4>(stage, lane, pc, vrec, kVertexDoubles, 4);
+            }
+            {
+                v2d pc[4] = {mk2(v0.sp.Ts.y, v0.sp.Ts.z), mk2(v0.sp.Bs.x, v0.sp.Bs.y), mk2(v0.sp.Bs.z, v0.a.x), mk2(v0.a.y, v0.a.z)};
+                waveStore<4>(stage, lane, pc, vrec, kVertexDoubles, 8);
+            }
+        }
+        {   // line 0 of the carry record, count word included
+            v2d pc[4] = {mk2(cy.pos.x, cy.pos.y), mk2(cy.pos.z, cy.dir.x), mk2(cy.dir.y, cy.dir.z), mk2(cy.p_psa, meta1)};
+            waveStore<4>(stage, lane, pc, crec, kCarryDoubles, 0);
+        }
+        if (light) {   // (the rest of an eye subpath's first record is constant, see loadCarry)
+            v2d pc[4] = {mk2(cy.a.x, cy.a.y), mk2(cy.a.z, cy.Ns.x), mk2(cy.Ns.y, cy.Ns.z), mk2(cy.q, cy.pending)};
+            waveStore<4>(stage, lane, pc, crec, kCarryDoubles, 4);
+        }
+        return;
+    }
+    if (id >= 2 * N) return;
+    if (!light) {
+        storeLensVertex(A.E, i, v0);
+        A.E.setMeta(i, 1);
+        storeCarryRay(A, id, cy);
+    } else if (live) {
+        storeVertex(A.L, 0, i, v0);
+        A.L.setMeta(i, 1);
+        storeCarry(A, id, cy);
+    } else {
+        A.L.setMeta(i, 0);
     }
 }
 
