@@ -233,6 +233,25 @@ DEV void waveStore(v2d* stage, int lane, const v2d (&piece)[PIECES], double* dst
     __builtin_amdgcn_wave_barrier();
 }
 DEV v2d mk2(double a, double b) { v2d v; v.x = a; v.y = b; return v; }
+// The lanes with `on` set hand in PIECES pieces each, which go to consecutive records of PIECES pieces from dst0 on, in
+// lane order (the records of a queue whose places were handed out by a ballot). Every lane of the wave must call.
+template <int PIECES>
+DEV void waveStoreRanked(v2d* stage, int lane, bool on, const v2d (&piece)[PIECES], double* dst0) {
+    static_assert(PIECES <= kStagePieces, "stage too small");
+    const unsigned long long m = __ballot(on);
+    const int rank = __popcll(m & ((1ULL << lane) - 1ULL)), count = __popcll(m);
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) stage[rank * PIECES + k] = piece[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const int p = k * 64 + lane;
+        if (p < count * PIECES) *reinterpret_cast<v2d*>(dst0 + 2 * p) = stage[p];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ---- generation ---------------------------------------------------------------------------------------
 // Vertex 0 and the first ray of every subpath (eye: lens vertex and primary ray, :231-257; light: emitter vertex and

@@ -480,6 +480,7 @@ template <bool STATS>
 __global__ __launch_bounds__(kBlock) void k_pair_setup(RenderArgs A) {
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
+    __shared__ v2d s_stage[kBlock / 64][64 * kStagePieces];
     const DScene& S = A.S;
     const uint32_t tid = threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * kBlock;
@@ -513,14 +514,17 @@ __global__ __launch_bounds__(kBlock) void k_pair_setup(RenderArgs A) {
             }
         }
         const uint32_t pos = blockAppend(ok, A.ray_count, s_wave, &s_base);
-        if (ok) {  // rays never outnumber pairs, and the ray queue holds as many entries as the pair queue
-            const double dist = length(epos - lpos);
-            const d3 dir = (epos - lpos) / dist;
-            double* o = A.rays + (uint64_t)pos * kRayDoubles;
-            o[0] = lpos.x; o[1] = lpos.y; o[2] = lpos.z;
-            o[3] = dir.x; o[4] = dir.y; o[5] = dir.z;
-            o[6] = dist;
-            A.ray_pairs[pos] = p;
+        // rays never outnumber pairs, and the ray queue holds as many entries as the pair queue. The rays of a wave's
+        // lanes go to consecutive places of the queue: written together, as whole lines (waveStoreRanked)
+        const double dist = length(epos - lpos);
+        const d3 dir = (epos - lpos) / dist;
+        const unsigned long long okm = __ballot(ok);
+        if (okm) {
+            const int lane = (int)(tid & 63);
+            const uint32_t first = __shfl(pos, __ffsll((long long)okm) - 1, 64);   // place of the wave's first ray
+            v2d pc[4] = {mk2(lpos.x, lpos.y), mk2(lpos.z, dir.x), mk2(dir.y, dir.z), mk2(dist, 0.0)};
+            waveStoreRanked<4>(s_stage[tid >> 6], lane, ok, pc, A.rays + (uint64_t)first * kRayDoubles);
+            if (ok) A.ray_pairs[pos] = p;
         }
     }
     if (STATS) flushTally(ty, A.counters, 0, 0);

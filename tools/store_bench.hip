@@ -7,6 +7,13 @@
 //   transposed  a wave stages its 64 records in LDS and writes them out so that consecutive lanes store consecutive
 //               16-byte pieces (every store instruction is coalesced)
 //   record8     the record pattern with 8-byte stores
+//   permuted    as record, but the records of a workgroup's 256 lanes are permuted among the lanes (what a kernel sees
+//               whose lanes were sorted by material) and every third record is left out (subpaths that ended)
+//   permuted-coop  the same records, staged in LDS together with their addresses; consecutive lanes then store
+//               consecutive pieces of ONE record (a store instruction touches 64 / pieces records instead of 64)
+// and the same questions for kernels that only READ records (sum of what they read, so that nothing is optimised away):
+//   read-record / read-permuted / read-permuted-coop (the lanes of a wave fetch the pieces of their 64 records so that
+//   consecutive lanes load consecutive pieces of ONE record, through LDS) / read-coalesced
 // Usage: store_bench [records (default 2^24)] [record bytes (default 192)]
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -61,6 +68,87 @@ __global__ __launch_bounds__(256) void k_transposed(double* out, unsigned long l
     }
 }
 
+__device__ __forceinline__ unsigned permute256(unsigned t) { return (t * 101u + 37u) & 255u; }   // a bijection on 0..255
+template <int PIECES>
+__global__ __launch_bounds__(256) void k_permuted(double* out, unsigned long long n) {
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + permute256(threadIdx.x);
+    if (i >= n || i % 3 == 2) return;
+    double* r = out + i * (2 * PIECES);
+    double x = (double)i;
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        v2d v; v.x = x + k; v.y = x - k;
+        *reinterpret_cast<v2d*>(r + 2 * k) = v;
+    }
+}
+template <int PIECES>
+__global__ __launch_bounds__(256) void k_permuted_coop(double* out, unsigned long long n) {
+    __shared__ v2d stage[4][64 * PIECES];
+    __shared__ double* dst[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + permute256(threadIdx.x);
+    const bool on = i < n && i % 3 != 2;
+    double x = (double)i;
+    dst[wave][lane] = on ? out + i * (2 * PIECES) : nullptr;
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        v2d v; v.x = x + k; v.y = x - k;
+        stage[wave][lane * PIECES + k] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const int p = k * 64 + lane;
+        const int r = p / PIECES, q = p - r * PIECES;
+        double* d = dst[wave][r];
+        if (d) *reinterpret_cast<v2d*>(d + 2 * q) = stage[wave][p];
+    }
+}
+
+template <int PIECES, bool PERMUTED>
+__global__ __launch_bounds__(256) void k_read_record(const double* in, unsigned long long n, double* sink) {
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + (PERMUTED ? permute256(threadIdx.x) : threadIdx.x);
+    if (i >= n || (PERMUTED && i % 3 == 2)) return;
+    const double* r = in + i * (2 * PIECES);
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        v2d v = *reinterpret_cast<const v2d*>(r + 2 * k);
+        acc += v.x + v.y;
+    }
+    if (acc == 12345.678) *sink = acc;
+}
+template <int PIECES>
+__global__ __launch_bounds__(256) void k_read_coop(const double* in, unsigned long long n, double* sink) {
+    __shared__ v2d stage[4][64 * PIECES];
+    __shared__ const double* src[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + permute256(threadIdx.x);
+    const bool on = i < n && i % 3 != 2;
+    src[wave][lane] = on ? in + i * (2 * PIECES) : nullptr;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const int p = k * 64 + lane;
+        const int r = p / PIECES, q = p - r * PIECES;
+        const double* d = src[wave][r];
+        v2d v; v.x = 0; v.y = 0;
+        if (d) v = *reinterpret_cast<const v2d*>(d + 2 * q);
+        stage[wave][p] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    double acc = 0;
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) { v2d v = stage[wave][lane * PIECES + k]; acc += v.x + v.y; }
+    if (acc == 12345.678) *sink = acc;
+}
+__global__ __launch_bounds__(256) void k_read_coalesced(const double* in, unsigned long long pieces, double* sink) {
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pieces) return;
+    v2d v = *reinterpret_cast<const v2d*>(in + 2 * i);
+    if (v.x + v.y == 12345.678) *sink = v.x;
+}
+
 template <class F>
 static float best_of(int reps, F&& launch) {
     hipEvent_t a, b;
@@ -91,6 +179,20 @@ static void run(double* out, unsigned long long n) {
     printf("%3d-byte records  record8     %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb / t * 1e3);
     t = best_of(5, [&] { hipLaunchKernelGGL(k_transposed<PIECES>, dim3(blocks), dim3(256), 0, 0, out, n); });
     printf("%3d-byte records  transposed  %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb / t * 1e3);
+    const double gb23 = gb * 2 / 3;
+    t = best_of(5, [&] { hipLaunchKernelGGL(k_permuted<PIECES>, dim3(blocks), dim3(256), 0, 0, out, n); });
+    printf("%3d-byte records  permuted       %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
+    t = best_of(5, [&] { hipLaunchKernelGGL(k_permuted_coop<PIECES>, dim3(blocks), dim3(256), 0, 0, out, n); });
+    printf("%3d-byte records  permuted-coop  %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
+    double* sink = out + n * 24;
+    t = best_of(5, [&] { hipLaunchKernelGGL(k_read_coalesced, dim3((unsigned)((n * PIECES + 255) / 256)), dim3(256), 0, 0, out, n * PIECES, sink); });
+    printf("%3d-byte records  read-coalesced      %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb / t * 1e3);
+    t = best_of(5, [&] { hipLaunchKernelGGL((k_read_record<PIECES, false>), dim3(blocks), dim3(256), 0, 0, out, n, sink); });
+    printf("%3d-byte records  read-record         %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb / t * 1e3);
+    t = best_of(5, [&] { hipLaunchKernelGGL((k_read_record<PIECES, true>), dim3(blocks), dim3(256), 0, 0, out, n, sink); });
+    printf("%3d-byte records  read-permuted       %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
+    t = best_of(5, [&] { hipLaunchKernelGGL(k_read_coop<PIECES>, dim3(blocks), dim3(256), 0, 0, out, n, sink); });
+    printf("%3d-byte records  read-permuted-coop  %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
 }
 
 int main(int argc, char** argv) {
