@@ -182,6 +182,7 @@ struct ubdpt_context {
     uint32_t pool_pages = 0;
     uint32_t fb_lane_slots = 1;    // sum buffers per lane: the passes a batch may touch when they are kept apart, else one
     uint64_t batches_redone = 0;
+    double tree_build_seconds = 0;   // buildLbvh alone (UBDPT_CREATE_TIMES prints the phases of ubdpt_create)
     std::vector<BatchLane> lanes;
     uint64_t next_batch = 0;      // batches enqueued so far; batch k runs on lane k % lanes.size()
     // ubdpt_query_progress reads these without the context mutex (an enqueue call holds that one while it waits for room on
@@ -461,7 +462,10 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
     Prim* d_unsorted = nullptr;
     HIPCK(c, upload(&d_unsorted, prims));
     BvhBuildResult br;
+    const double tb0 = nowSeconds();
     hipError_t be = buildLbvh(c->d_objects, d_unsorted, (uint32_t)prims.size(), c->stream, &br);
+    if (be == hipSuccess) be = hipStreamSynchronize(c->stream);
+    c->tree_build_seconds = nowSeconds() - tb0;
     hipFree(d_unsorted);
     HIPCK(c, be);
     c->d_nodes = br.nodes;
@@ -575,10 +579,12 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
     if (c->opt.max_path_vertices > 255) c->opt.max_path_vertices = 255;
     c->params = *params;
     int st = UBDPT_SUCCESS;
+    double t_scene = t0;
     do {
         if (hipSetDevice(device) != hipSuccess) { st = UBDPT_HIP_ERROR; break; }
         if (hipStreamCreate(&c->stream) != hipSuccess) { st = UBDPT_HIP_ERROR; break; }
         if ((st = flattenAndUpload(c, scene)) != UBDPT_SUCCESS) break;
+        t_scene = nowSeconds();
         c->npix = params->img_res_x * params->img_res_y;
         // passes in flight: enough paths to fill 256 CUs several times over, bounded by vertex storage
         // (per pixel-sample: vertex records and count words of both subpaths, pair / ray / visible-pair queues of
@@ -745,6 +751,9 @@ int ubdpt_create(const ubdpt_scene_desc* scene, const ubdpt_render_params* param
         return st;
     }
     c->stats.build_seconds = nowSeconds() - t0;
+    if (getenv("UBDPT_CREATE_TIMES"))
+        fprintf(stderr, "ubdpt_create: %.3f s (scene flattened, uploaded and tree built %.3f s, of which the tree %.3f s; batch buffers %.3f s)\n",
+                c->stats.build_seconds, t_scene - t0, c->tree_build_seconds, nowSeconds() - t_scene);
     *out = c;
     return UBDPT_SUCCESS;
 }
