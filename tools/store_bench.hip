@@ -150,6 +150,29 @@ __global__ __launch_bounds__(256) void k_read_coalesced(const double* in, unsign
     if (v.x + v.y == 12345.678) *sink = v.x;
 }
 
+// every lane reads one record at a pseudo-random place of the array (a gather of whole records: what the connection
+// kernels do with vertex records and the ray tracing kernels with tree nodes)
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+template <int PIECES>
+__global__ __launch_bounds__(256) void k_read_random(const double* in, unsigned long long n, double* sink, int rounds) {
+    unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    double acc = 0;
+    for (int r = 0; r < rounds; r++) {
+        const unsigned long long j = mix64(i * rounds + r + 77) % n;
+        const double* rec = in + j * (2 * PIECES);
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            v2d v = *reinterpret_cast<const v2d*>(rec + 2 * k);
+            acc += v.x + v.y;
+        }
+    }
+    if (acc == 12345.678) *sink = acc;
+}
+
 template <class F>
 static float best_of(int reps, F&& launch) {
     hipEvent_t a, b;
@@ -194,6 +217,9 @@ static void run(double* out, unsigned long long n) {
     printf("%3d-byte records  read-permuted       %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
     t = best_of(5, [&] { hipLaunchKernelGGL(k_read_coop<PIECES>, dim3(blocks), dim3(256), 0, 0, out, n, sink); });
     printf("%3d-byte records  read-permuted-coop  %.3f ms  %.0f GB/s\n", 16 * PIECES, t, gb23 / t * 1e3);
+    // 2^22 lanes x 4 rounds = as many records as the array holds, each at a random place
+    t = best_of(5, [&] { hipLaunchKernelGGL(k_read_random<PIECES>, dim3((unsigned)(n / 4 / 256)), dim3(256), 0, 0, out, n, sink, 4); });
+    printf("%3d-byte records  read-random         %.3f ms  %.0f GB/s  (%.1f G records/s)\n", 16 * PIECES, t, gb / t * 1e3, n / t * 1e-6);
 }
 
 int main(int argc, char** argv) {
