@@ -375,6 +375,15 @@ int flattenAndUpload(ubdpt_context* c, const ubdpt_scene_desc* sd) {
             face_attr[f].uv[2 * v] = mv.uv[0];
             face_attr[f].uv[2 * v + 1] = mv.uv[1];
         }
+        {   // the geometric normal of uapp/mesh.cpp:150, from the float corners (see FaceAttr)
+            const float* p = &face_pos[9 * f];
+            const d3 p0 = mk3((double)p[0], (double)p[1], (double)p[2]);
+            const d3 p1 = mk3((double)p[3], (double)p[4], (double)p[5]);
+            const d3 p2 = mk3((double)p[6], (double)p[7], (double)p[8]);
+            const d3 ng = normalize(cross(p1 - p0, p2 - p0));
+            face_attr[f].Ng[0] = ng.x; face_attr[f].Ng[1] = ng.y; face_attr[f].Ng[2] = ng.z;
+            face_attr[f].pad = 0;
+        }
     }
     c->h_objects.resize(sd->num_objects);
     for (uint32_t i = 0; i < sd->num_objects; i++) {

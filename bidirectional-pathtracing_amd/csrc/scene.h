@@ -100,13 +100,19 @@ struct __attribute__((aligned(16))) Prim {
 static_assert(sizeof(Prim) == UBDPT_PRIM_BYTES && (UBDPT_PRIM_BYTES == 48 || UBDPT_PRIM_BYTES == 64), "Prim is 48 or 64 bytes");
 constexpr uint32_t kSphereFace = 0xffffffffu;
 
-// Per-face shading attributes (normals, tangents, uv of the three corners), object order.
+// Per-face shading record, object order: normals, tangents, uv of the three corners, and the face's geometric normal
+// normalize(cross(p1 - p0, p2 - p0)) of uapp/mesh.cpp:150, computed once from the float corners with the operations the
+// kernels would use (before the flip towards the shading normal, which depends on the hit). One 128-byte line, the
+// unit the memory system moves: shading a hit fetches this line and nothing else of the face (the corner positions and
+// a 96-byte attribute record were three lines per hit, and a third of the shading kernel's time on a 2 M-triangle scene).
 struct FaceAttr {
     float n[9];
     float t[9];
     float uv[6];
+    double Ng[3];
+    double pad;
 };
-static_assert(sizeof(FaceAttr) == 96, "FaceAttr must be 96 bytes");
+static_assert(sizeof(FaceAttr) == 128, "FaceAttr must be one 128-byte line");
 
 // Everything the kernels need, passed by value as a kernel argument.
 struct DScene {

@@ -453,14 +453,12 @@ DEV void surfacePoint(const DScene& S, const Ray& r, const Closest& h, SurfacePo
         sp.Ts = normalize(-sp.Ns + mk3(0, 0, 1.0 / sp.Ns.z));
         sp.Bs = normalize(cross(sp.Ns, sp.Ts));
     } else {  // uapp/mesh.cpp:144-156
-        const float* p = S.face_pos + 9 * (ob.first_face + h.face);
         const FaceAttr& fa = S.face_attr[ob.first_face + h.face];
         double w0 = 1.0 - h.u - h.v;
         sp.tex_u = w0 * (double)fa.uv[0] + h.u * (double)fa.uv[2] + h.v * (double)fa.uv[4];
         sp.tex_v = w0 * (double)fa.uv[1] + h.u * (double)fa.uv[3] + h.v * (double)fa.uv[5];
         sp.Ns = normalize(w0 * loadP(fa.n) + h.u * loadP(fa.n + 3) + h.v * loadP(fa.n + 6));
-        d3 p0 = loadP(p);
-        sp.Ng = normalize(cross(loadP(p + 3) - p0, loadP(p + 6) - p0));
+        sp.Ng = mk3(fa.Ng[0], fa.Ng[1], fa.Ng[2]);
         if (dot(sp.Ns, sp.Ng) < 0) sp.Ng = sp.Ng * -1.0;
         sp.Ts = normalize(w0 * loadP(fa.t) + h.u * loadP(fa.t + 3) + h.v * loadP(fa.t + 6));
         sp.Bs = normalize(cross(sp.Ns, sp.Ts));
