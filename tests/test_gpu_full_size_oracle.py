@@ -156,3 +156,27 @@ def test_relmse_against_a_sixteen_times_spp_reference(name, w, h, accel):
     assert 0.9 * min(plain) <= g_plain <= 1.1 * max(plain)
     m_gpu, m_ref = gpu.reshape(-1, 3).mean(0), ref_inf.reshape(-1, 3).mean(0)
     assert np.all(np.abs(m_gpu - m_ref) / m_ref < 0.01)
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_connection_probes_at_full_triangle_count(name):
+    """connectionFactor (with its visibility test through the device tree), weight and s0sample
+    (ubdptrenderer.cpp:156-222, 596-844) on the subpaths the oracle's tree mode traces for a hundred pixels of the mesh
+    workloads at their full triangle counts: the same (s, t) connect, c, w and the s = 0 value agree to 1e-12."""
+    from test_gpu_parity import _probe_compare
+    scene, _, _ = config(name)
+    w, h = 96, 54
+    orc = oracle_tree(name, w, h)
+    rng = np.random.default_rng(11)
+    n_conn = n_s0 = 0
+    worst = 0.0
+    with capi.Context(scene, scenes.make_params(w, h)) as ctx:
+        for _ in range(100):
+            px, py, p = int(rng.integers(0, w)), int(rng.integers(0, h)), int(rng.integers(0, 8))
+            eye, light, I, splats = orc.trace_pixel(p, SEED, px, py)
+            if len(light) == 0 or len(eye) == 0:
+                continue
+            a, b, wv = _probe_compare(ctx, orc, eye, light, f"{name} pixel {px},{py} pass {p}")
+            n_conn += a; n_s0 += b; worst = max(worst, wv)
+    print(f"{name}: {n_conn} connected pairs, {n_s0} s=0 samples, worst relative deviation {worst:.2e}")
+    assert n_conn > 200 and worst <= 1e-12
