@@ -68,16 +68,18 @@ def test_hit_identity_equals_oracle_at_full_triangle_count(name):
         assert deepest > 16   # beyond the part of the stack kept on chip
 
 
+@pytest.mark.parametrize("pipeline", [0, 1])
 @pytest.mark.parametrize("name", ["C3", "C4", "C5"])
-def test_image_equals_oracle_path_by_path_at_full_triangle_count(name):
+def test_image_equals_oracle_path_by_path_at_full_triangle_count(name, pipeline):
     """Three passes at 96 x 54 on the full geometry, default pipeline (persistent-wave trace kernels, ray queues, the
-    traversal stacks' overflow in HBM), same seed as the oracle's tree mode: at most 0.2 % of the pixels may differ by
+    traversal stacks' overflow in HBM) and the per-path cross-check pipeline, same seed as the oracle's tree mode: at most 0.2 % of the pixels may differ by
     more than 1e-9 relative, relMSE <= 2e-3, channel means within 0.5 %, vertex and connection counts within 0.5 %."""
     scene, _, _ = config(name)
     w, h, passes = 96, 54, 3
     orc = oracle_tree(name, w, h)
     opt = capi.Options()
     opt.collect_stats = 1
+    opt.pipeline = pipeline
     with capi.Context(scene, scenes.make_params(w, h), opt) as ctx:
         st, done = ctx.render_passes(0, passes, SEED)
         assert st == capi.SUCCESS and done == passes
@@ -89,7 +91,7 @@ def test_image_equals_oracle_path_by_path_at_full_triangle_count(name):
     g, r = np.where(fin[..., None], got, 0) / passes, np.where(fin[..., None], ref, 0) / passes
     err = np.abs(g - r) / np.maximum(np.abs(r), 1e-3)
     bad = float(np.any(err > 1e-9, axis=2).mean())
-    print(f"{name} at full triangle count vs oracle tree mode: {bad * 100:.3f} % of pixels off by > 1e-9")
+    print(f"{name}, pipeline {pipeline}, at full triangle count vs oracle tree mode: {bad * 100:.3f} % of pixels off by > 1e-9")
     assert r.sum() > 0 and bad <= 0.002, bad
     assert rel_mse(g, r) <= 2e-3
     mg, mr = g.reshape(-1, 3).mean(0), r.reshape(-1, 3).mean(0)
@@ -158,7 +160,7 @@ def test_relmse_against_a_sixteen_times_spp_reference(name, w, h, accel):
     assert np.all(np.abs(m_gpu - m_ref) / m_ref < 0.01)
 
 
-@pytest.mark.parametrize("name", ["C3", "C4"])
+@pytest.mark.parametrize("name", ["C3", "C4", "C5"])
 def test_connection_probes_at_full_triangle_count(name):
     """connectionFactor (with its visibility test through the device tree), weight and s0sample
     (ubdptrenderer.cpp:156-222, 596-844) on the subpaths the oracle's tree mode traces for a hundred pixels of the mesh
